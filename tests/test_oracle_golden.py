@@ -1,0 +1,143 @@
+"""Pins the CPU oracle (oracle/siv_oracle.py) against fixtures produced by the
+imported reference (tools/make_goldens.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import siv_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL, ATOL = 1e-5, 1e-6      # same library, same machine class: only op-ordering noise is expected
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def sd_from(g, prefix):
+    return {k[len(prefix):]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(prefix)}
+
+
+def close(a, b, rtol=RTOL, atol=ATOL, what=""):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, np.asarray(b), rtol=rtol, atol=atol, err_msg=what)
+
+
+@pytest.mark.parametrize("name", ["bb_s1", "bb_s2", "bb_s1p", "ub_s1", "ub_s2", "vbb_s2", "vub_s2"])
+def test_g2_blocks(name):
+    g = load("g2_blocks.npz")
+    cin, cout, s = (int(v) for v in g[name + ".meta"])
+    sd = sd_from(g, name + ".sd0.")
+    x = torch.from_numpy(g[name + ".x"])
+    slope = 0.0 if name.startswith("v") else 0.2
+    fn = O.upsample_block if "ub" in name else O.building_block
+    y = fn(x, sd, "", cin, cout, s, slope, True)
+    close(y, g[name + ".y"], what="train output")
+    sd1 = sd_from(g, name + ".sd1.")
+    for k in sd1:
+        close(sd[k], sd1[k], what=k)
+    y_eval = fn(x, sd, "", cin, cout, s, slope, False)
+    close(y_eval, g[name + ".y_eval"], what="eval output")
+
+
+def test_g3_model():
+    g = load("g3_model.npz")
+    cfg = O.Cfg(4, [[4, 1, 2], [8, 1, 2], [8, 2, 2]])
+    sd = sd_from(g, "sd0.")
+    x, z_in = torch.from_numpy(g["x"]), torch.from_numpy(g["z_in"])
+    draws = O.Draws(seed=int(g["draw_seed"]))
+    mu, lv = O.encode(x, sd, cfg, draws, True)
+    xd = O.decode(z_in, sd, cfg, draws, True)
+    fmu, flv, fz, fx = O.forward(x, sd, cfg, draws, True)
+    assert draws.i == int(g["n_draws"])
+    for a, k in ((mu, "enc.mu"), (lv, "enc.logvar"), (xd, "dec.x"), (fmu, "fwd.mu"),
+                 (flv, "fwd.logvar"), (fz, "fwd.z"), (fx, "fwd.x")):
+        close(a, g[k], what=k)
+    sd1 = sd_from(g, "sd1.")
+    for k in sd1:
+        close(sd[k], sd1[k], what=k)
+    mu, lv = O.encode(x, sd, cfg, None, False)
+    z = O.reparameterize(mu, lv, None, True)
+    xe = O.decode(z, sd, cfg, None, False)
+    for a, k in ((mu, "eval.mu"), (lv, "eval.logvar"), (z, "eval.z"), (xe, "eval.x")):
+        close(a, g[k], what=k)
+
+
+def test_g4_step():
+    g = load("g4_step.npz")
+    cfg = O.Cfg(4, [[4, 1, 2], [8, 1, 2], [8, 2, 2]])
+    sd = sd_from(g, "sd0.")
+    hp = O.Hyper(beta_rec=float(g["hp.beta_rec"]), beta_neg=float(g["hp.beta_neg"]),
+                 beta_kl=float(g["hp.beta_kl"]), gamma_r=float(g["hp.gamma_r"]),
+                 scale=float(g["hp.scale"]))
+    draws = O.Draws(seed=int(g["draw_seed"]))
+    ae, ad = {}, {}
+    for step in range(2):
+        real = torch.from_numpy(g[f"s{step}.real"])
+        noise = torch.from_numpy(g[f"s{step}.noise"])
+        r = O.soft_intro_step(sd, cfg, real, noise, draws, hp, ae, ad)
+        for k in ("lossE", "lossD", "loss_rec_E", "loss_rec_D", "kl_real", "rec_kl", "fake_kl",
+                  "fake_kl_e", "rec_kl_e"):
+            close(r[k], g[f"s{step}.{k}"], rtol=2e-5, what=f"s{step}.{k}")
+        for k in ("exp_elbo_fake", "exp_elbo_rec"):
+            close(r[k], g[f"s{step}.{k}"], rtol=1e-3, atol=1e-30, what=k)
+        for which in ("gradE", "gradD"):
+            for pk, gr in r[which].items():
+                key = f"s{step}.{which}.{pk}"
+                if gr is None:
+                    assert key + ".none" in g.files, key
+                else:
+                    ref = g[key]
+                    # gradients that are analytically ~0 (a conv scale/bias that the
+                    # following BatchNorm cancels) are rounding noise: absolute floor
+                    tol = 2e-5 * float(np.abs(ref).max()) + 3e-7
+                    close(gr, ref, rtol=1e-4, atol=tol, what=key)
+        ref_sd = sd_from(g, f"s{step}.sd.")
+        for k in ref_sd:
+            # Adam normalises the step by |g|: a parameter whose gradient is pure rounding
+            # noise still moves by up to lr per step, in a noise-determined direction
+            gk = [f"s{step}.{w}.{k}" for w in ("gradE", "gradD")]
+            noise = any(q in g.files and float(np.abs(g[q]).max()) < 1e-5 for q in gk)
+            close(sd[k], ref_sd[k], rtol=1e-5, atol=(2 * (step + 1) * hp.lr if noise else 2e-6),
+                  what=f"s{step}.sd.{k}")
+    assert draws.i == int(g["n_draws"])
+
+
+def test_g5_losses():
+    g = load("g5_losses.npz")
+    mu, lv = torch.from_numpy(g["mu"]), torch.from_numpy(g["logvar"])
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    for r in ("mean", "sum", "none"):
+        close(O.calc_kl(lv, mu, r), g["kl." + r], what=r)
+    for r in ("mean", "None", "none"):
+        close(O.calc_reconstruction_loss(x, y, r), g["rec." + r], what=r)
+    loss, mse, kld = O.normal_loss(y, mu, lv, x, 1, 10)
+    close(torch.stack([loss, mse, kld]), g["normal_loss"])
+    close(O.calc_kl(lv, mu, "mean"), g["lossf.kld"])
+    close(O.calc_reconstruction_loss(x, y, "mean"), g["lossf.mse"])
+
+
+def test_g6_vae():
+    g = load("g6_vae.npz")
+    cfg = O.Cfg(4, [[4, 1, 2], [6, 1, 2], [8, 2, 2], [12, 2, 2]], variant="vae")
+    sd = sd_from(g, "sd0.")
+    draws = O.Draws(seed=int(g["draw_seed"]))
+    adam = {}
+    for step in range(2):
+        x = torch.from_numpy(g[f"s{step}.x"])
+        r = O.vae_step(sd, cfg, x, draws, 1, 20, 1e-3, adam)
+        close(torch.stack([r["loss"], r["mse"], r["kld"]]), g[f"s{step}.loss"], rtol=2e-5)
+        close(r["mu"], g[f"s{step}.mu"], rtol=1e-4, atol=1e-5)
+        close(r["x_re"][:, :, 16], g[f"s{step}.x_re_slice"], rtol=1e-4, atol=1e-5)
+        for pk, gr in r["grad"].items():
+            key = f"s{step}.grad.{pk}"
+            if gr is None:
+                assert key + ".none" in g.files, key
+            else:
+                ref = g[key]
+                close(gr, ref, rtol=1e-4, atol=2e-5 * float(np.abs(ref).max()) + 3e-7, what=key)
+        ref_sd = sd_from(g, f"s{step}.sd.")
+        for k in ref_sd:
+            close(sd[k], ref_sd[k], rtol=1e-5, atol=5e-6, what=f"s{step}.sd.{k}")

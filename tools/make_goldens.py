@@ -1,0 +1,428 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported from
+/root/reference) on the CPU in the build container.
+
+The reference's stochastic ops (nn.Dropout, torch.randn_like, torch.randn) are
+patched for the duration of each run so that they hand out the deterministic
+tensors of ``oracle.siv_oracle.Draws`` -- the fixtures then store only a seed,
+and the oracle / HIP path replay the same draws.  Nothing from the reference is
+written into the fixtures except numbers it computed.
+
+Usage:  python tools/make_goldens.py [--only g4]      (needs /root/reference)
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("SIV_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle.siv_oracle import Draws  # noqa: E402
+
+
+def _stub_missing_modules():
+    """utils/my_trainer.py imports plotting / sklearn-wrapper packages that are
+    not installed here and are not on the arithmetic path (they are used only
+    by save_image and by unrelated classifier trainers)."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+    try:
+        import asyncore  # noqa: F401
+    except Exception:
+        mod("asyncore", loop=lambda *a, **k: None)
+    try:
+        import skimage.metrics  # noqa: F401
+    except Exception:
+        mod("skimage")
+        mod("skimage.metrics",
+            mean_squared_error=lambda a, b: float(np.mean((np.asarray(a) - np.asarray(b)) ** 2)),
+            structural_similarity=lambda a, b, **k: 0.0)
+    try:
+        import skorch  # noqa: F401
+    except Exception:
+        mod("skorch", NeuralNetClassifier=object)
+        mod("skorch.callbacks", Callback=object, Checkpoint=object, EarlyStopping=object)
+        mod("skorch.dataset", CVSplit=object)
+    try:
+        import tune_sklearn  # noqa: F401
+    except Exception:
+        mod("tune_sklearn", TuneSearchCV=object, TuneGridSearchCV=object)
+    import matplotlib
+    matplotlib.use("Agg")
+
+
+@contextlib.contextmanager
+def patched_random(draws: Draws):
+    """Route the reference's random draws through ``draws``."""
+    orig_fwd, orig_rl = nn.Dropout.forward, torch.randn_like
+
+    def drop_fwd(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        keep = draws.mask(x.shape, self.p)
+        return x * keep * (1.0 / (1.0 - self.p))
+
+    nn.Dropout.forward = drop_fwd
+    torch.randn_like = lambda t, **kw: draws.eps(t.shape)
+    try:
+        yield
+    finally:
+        nn.Dropout.forward = orig_fwd
+        torch.randn_like = orig_rl
+
+
+def sd_np(sd, prefix=""):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in sd.items()}
+
+
+def randomize_affine(net, gen):
+    """Move BN gamma/beta and running stats off their 1/0 defaults so that the
+    fixtures exercise them."""
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, nn.BatchNorm3d):
+                m.weight.copy_(1.0 + 0.2 * torch.randn(m.weight.shape, generator=gen))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+                m.running_mean.copy_(0.05 * torch.randn(m.bias.shape, generator=gen))
+                m.running_var.copy_(1.0 + 0.1 * torch.rand(m.bias.shape, generator=gen))
+
+
+def he_init(net):
+    for m in net.modules():
+        if type(m) == nn.Conv3d:
+            nn.init.kaiming_normal_(m.weight, nonlinearity="leaky_relu")
+
+
+# ---------------------------------------------------------------- G2 blocks
+def g2_blocks():
+    import models.models as M
+    import models.vaemodel as MV
+    out = {}
+    gen = torch.Generator().manual_seed(2)
+    cases = [("bb_s1", M.BuildingBlock, 6, 6, 1), ("bb_s2", M.BuildingBlock, 4, 8, 2),
+             ("bb_s1p", M.BuildingBlock, 4, 6, 1),
+             ("ub_s1", M.UpsampleBuildingkBlock, 6, 6, 1), ("ub_s2", M.UpsampleBuildingkBlock, 8, 4, 2),
+             ("vbb_s2", MV.BuildingBlock, 4, 8, 2), ("vub_s2", MV.UpsampleBuildingkBlock, 8, 4, 2)]
+    for name, cls, cin, cout, s in cases:
+        torch.manual_seed(20 + len(out))
+        blk = cls(cin, cout, s)
+        he_init(blk)
+        randomize_affine(blk, gen)
+        blk.train()
+        x = torch.randn(3, cin, 6, 8, 4, generator=gen)
+        out.update(sd_np(blk.state_dict(), f"{name}.sd0."))
+        y = blk(x)
+        out[f"{name}.x"] = x.numpy()
+        out[f"{name}.y"] = y.detach().numpy()
+        out.update(sd_np(blk.state_dict(), f"{name}.sd1."))
+        blk.eval()
+        out[f"{name}.y_eval"] = blk(x).detach().numpy()
+        out[f"{name}.meta"] = np.array([cin, cout, s])
+    np.savez_compressed(os.path.join(OUT, "g2_blocks.npz"), **out)
+    print("g2_blocks", len(out))
+
+
+SMALL = (4, [[4, 1, 2], [8, 1, 2], [8, 2, 2]])
+SMALL_DIMS = (16, 24, 16)
+
+
+def build_small(seed=82):
+    import models.models as M
+    torch.manual_seed(seed)
+    net = M.SoftIntroVAE(*SMALL)
+    torch.manual_seed(77)
+    he_init(net)
+    randomize_affine(net, torch.Generator().manual_seed(5))
+    return net
+
+
+# ---------------------------------------------------------------- G3 model
+def g3_model():
+    net = build_small()
+    gen = torch.Generator().manual_seed(103)
+    x = torch.rand(3, 1, *SMALL_DIMS, generator=gen)
+    zz = torch.randn(3, 1, 2, 3, 2, generator=gen)
+    out = sd_np(net.state_dict(), "sd0.")
+    out["x"], out["z_in"] = x.numpy(), zz.numpy()
+    net.train()
+    draws = Draws(seed=31)
+    with patched_random(draws):
+        mu, lv = net.encode(x)
+        xd = net.decode(zz)
+        fmu, flv, fz, fx = net.forward(x)
+    out.update({"enc.mu": mu.detach().numpy(), "enc.logvar": lv.detach().numpy(),
+                "dec.x": xd.detach().numpy(), "fwd.mu": fmu.detach().numpy(),
+                "fwd.logvar": flv.detach().numpy(), "fwd.z": fz.detach().numpy(),
+                "fwd.x": fx.detach().numpy(), "draw_seed": np.array(31), "n_draws": np.array(draws.i)})
+    out.update(sd_np(net.state_dict(), "sd1."))
+    net.eval()
+    with torch.no_grad():
+        mu, lv = net.encode(x)
+        z = net.reparameterize(mu, lv, True)
+        xe = net.decode(z)
+    out.update({"eval.mu": mu.numpy(), "eval.logvar": lv.numpy(), "eval.z": z.numpy(), "eval.x": xe.numpy()})
+    np.savez_compressed(os.path.join(OUT, "g3_model.npz"), **out)
+    print("g3_model", len(out))
+
+
+# ---------------------------------------------------------------- G4 step
+def reference_step(net, T, real, noise, opt_e, opt_d, hp):
+    """Hand-driven copy of the *call sequence* of utils/my_trainer.py:242-325
+    on the imported reference model and loss functions (the trainer itself is
+    exercised end to end by g8)."""
+    scale, br, bn, bk, gr = hp["scale"], hp["beta_rec"], hp["beta_neg"], hp["beta_kl"], hp["gamma_r"]
+    rec_out = {}
+    for p in net.encoder.parameters():
+        p.requires_grad = True
+    for p in net.decoder.parameters():
+        p.requires_grad = False
+    fake = net.decode(noise)
+    real_mu, real_logvar = net.encode(real)
+    z = net.reparameterize(real_mu, real_logvar)
+    rec = net.decode(z)
+    loss_rec = T.calc_reconstruction_loss(real, rec, loss_type="mse", reduction="mean")
+    lossE_real_kl = T.calc_kl(real_logvar, real_mu, reduce="mean")
+    rec_mu, rec_logvar, z_rec, rec_rec = net.forward(rec.detach())
+    fake_mu, fake_logvar, z_fake, rec_fake = net.forward(fake.detach())
+    fake_kl_e = T.calc_kl(fake_logvar, fake_mu, reduce="none")
+    rec_kl_e = T.calc_kl(rec_logvar, rec_mu, reduce="none")
+    loss_fake_rec = T.calc_reconstruction_loss(fake, rec_fake, loss_type="mse", reduction="none")
+    loss_rec_rec = T.calc_reconstruction_loss(rec, rec_rec, loss_type="mse", reduction="none")
+    exp_elbo_fake = (-2 * scale * (br * loss_fake_rec + bn * fake_kl_e)).exp().mean()
+    exp_elbo_rec = (-2 * scale * (br * loss_rec_rec + bn * rec_kl_e)).exp().mean()
+    lossE = scale * (br * loss_rec + bk * lossE_real_kl) + 0.5 * (exp_elbo_fake + exp_elbo_rec)
+    lossE *= 10
+    opt_e.zero_grad()
+    lossE.backward()
+    rec_out["gradE"] = {k: (p.grad.detach().clone() if p.grad is not None else None)
+                        for k, p in net.encoder.named_parameters()}
+    opt_e.step()
+    rec_out.update(lossE=lossE.item(), loss_rec_E=loss_rec.item(), kl_real=lossE_real_kl.item(),
+                   exp_elbo_fake=exp_elbo_fake.item(), exp_elbo_rec=exp_elbo_rec.item(),
+                   fake_kl_e=fake_kl_e.detach().numpy().copy(), rec_kl_e=rec_kl_e.detach().numpy().copy(),
+                   loss_fake_rec_e=loss_fake_rec.detach().numpy().copy(),
+                   loss_rec_rec_e=loss_rec_rec.detach().numpy().copy())
+    for p in net.encoder.parameters():
+        p.requires_grad = False
+    for p in net.decoder.parameters():
+        p.requires_grad = True
+    fake = net.decode(noise)
+    rec = net.decode(z.detach())
+    loss_rec = T.calc_reconstruction_loss(real, rec, loss_type="mse", reduction="mean")
+    rec_mu, rec_logvar = net.encode(rec)
+    z_rec = net.reparameterize(rec_mu, rec_logvar)
+    fake_mu, fake_logvar = net.encode(fake)
+    z_fake = net.reparameterize(fake_mu, fake_logvar)
+    rec_rec = net.decode(z_rec.detach())
+    rec_fake = net.decode(z_fake.detach())
+    loss_rec_rec = T.calc_reconstruction_loss(rec.detach(), rec_rec, loss_type="mse", reduction="mean")
+    loss_fake_rec = T.calc_reconstruction_loss(fake.detach(), rec_fake, loss_type="mse", reduction="mean")
+    rec_kl = T.calc_kl(rec_logvar, rec_mu, reduce="mean")
+    fake_kl = T.calc_kl(fake_logvar, fake_mu, reduce="mean")
+    lossD = scale * (br * loss_rec + 0.5 * bk * (rec_kl + fake_kl) + gr * 0.5 * br * (loss_rec_rec + loss_fake_rec))
+    lossD *= 10
+    opt_d.zero_grad()
+    lossD.backward()
+    rec_out["gradD"] = {k: (p.grad.detach().clone() if p.grad is not None else None)
+                        for k, p in net.decoder.named_parameters()}
+    opt_d.step()
+    rec_out.update(lossD=lossD.item(), loss_rec_D=loss_rec.item(), rec_kl=rec_kl.item(), fake_kl=fake_kl.item())
+    return rec_out
+
+
+def g4_step():
+    _stub_missing_modules()
+    import utils.my_trainer as T
+    net = build_small()
+    net.train()
+    gen = torch.Generator().manual_seed(104)
+    B = 3
+    hp = dict(scale=8.0 / np.prod(SMALL_DIMS), beta_rec=1.0, beta_neg=1024.0, beta_kl=0.75, gamma_r=1e-8)
+    out = sd_np(net.state_dict(), "sd0.")
+    opt_e = torch.optim.Adam(net.encoder.parameters(), lr=2e-4)
+    opt_d = torch.optim.Adam(net.decoder.parameters(), lr=2e-4)
+    draws = Draws(seed=41)
+    with patched_random(draws):
+        for step in range(2):
+            real = torch.rand(B, 1, *SMALL_DIMS, generator=gen)
+            noise = torch.randn(B, 1, 2, 3, 2, generator=gen)
+            r = reference_step(net, T, real, noise, opt_e, opt_d, hp)
+            out[f"s{step}.real"], out[f"s{step}.noise"] = real.numpy(), noise.numpy()
+            for k, v in r.items():
+                if k in ("gradE", "gradD"):
+                    pre = "encoder." if k == "gradE" else "decoder."
+                    for pk, g in v.items():
+                        if g is not None:
+                            out[f"s{step}.{k}.{pre}{pk}"] = g.numpy()
+                        else:
+                            out[f"s{step}.{k}.{pre}{pk}.none"] = np.array(1)
+                else:
+                    out[f"s{step}.{k}"] = np.asarray(v)
+            out.update(sd_np(net.state_dict(), f"s{step}.sd."))
+    out["draw_seed"] = np.array(41)
+    out["n_draws"] = np.array(draws.i)
+    for k, v in hp.items():
+        out["hp." + k] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, "g4_step.npz"), **out)
+    print("g4_step", len(out), "draws", draws.i)
+
+
+# ---------------------------------------------------------------- G5 losses
+def g5_losses():
+    _stub_missing_modules()
+    import utils.my_trainer as T
+    import models.lossf as L
+    gen = torch.Generator().manual_seed(5)
+    mu = torch.randn(4, 1, 2, 3, 2, generator=gen) * 3
+    lv = torch.randn(4, 1, 2, 3, 2, generator=gen) * 2
+    lv[0, 0, 0, 0, 0] = 30.0
+    lv[1, 0, 0, 0, 0] = -30.0
+    x = torch.rand(4, 1, 6, 5, 7, generator=gen)
+    y = torch.rand(4, 1, 6, 5, 7, generator=gen)
+    out = {"mu": mu.numpy(), "logvar": lv.numpy(), "x": x.numpy(), "y": y.numpy()}
+    for r in ("mean", "sum", "none"):
+        out["kl." + r] = T.calc_kl(lv, mu, reduce=r).numpy()
+    for r in ("mean", "None", "none"):
+        out["rec." + r] = T.calc_reconstruction_loss(x, y, loss_type="mse", reduction=r).numpy()
+    loss, mse, kld = L.normal_loss(y, mu, lv, x, 1, 10)
+    out["normal_loss"] = np.array([loss.item(), mse.item(), kld.item()])
+    out["lossf.kld"] = L.kld_loss(mu, lv).numpy()
+    out["lossf.mse"] = L.mse_loss(y, x).numpy()
+    np.savez_compressed(os.path.join(OUT, "g5_losses.npz"), **out)
+    print("g5_losses", len(out))
+
+
+# ---------------------------------------------------------------- G6 plain VAE
+VAE_CFG = (4, [[4, 1, 2], [6, 1, 2], [8, 2, 2], [12, 2, 2]])
+
+
+def g6_vae():
+    import models.vaemodel as MV
+    import models.lossf as L
+    torch.manual_seed(82)
+    net = MV.ResNetVAE(*VAE_CFG)
+    torch.manual_seed(7)
+    for m in net.modules():
+        if type(m) == nn.Conv3d:
+            nn.init.kaiming_normal_(m.weight, nonlinearity="relu")
+    randomize_affine(net, torch.Generator().manual_seed(6))
+    net.train()
+    gen = torch.Generator().manual_seed(106)
+    opt = torch.optim.Adam(net.parameters(), 1e-3)
+    out = sd_np(net.state_dict(), "sd0.")
+    draws = Draws(seed=61)
+    with patched_random(draws):
+        for step in range(2):
+            x = torch.rand(2, 1, 32, 32, 32, generator=gen)
+            opt.zero_grad()
+            x_re, mu, logvar = net.forward(x)
+            loss, mse, kl = L.normal_loss(x_re, mu, logvar, x, 1, 20)
+            loss.backward()
+            for k, p in net.named_parameters():
+                if p.grad is not None:
+                    out[f"s{step}.grad.{k}"] = p.grad.detach().numpy().copy()
+                else:
+                    out[f"s{step}.grad.{k}.none"] = np.array(1)
+            opt.step()
+            out[f"s{step}.x"] = x.numpy()
+            out[f"s{step}.loss"] = np.array([loss.item(), mse.item(), kl.item()])
+            out[f"s{step}.mu"] = mu.detach().numpy()
+            out[f"s{step}.logvar"] = logvar.detach().numpy()
+            out[f"s{step}.x_re_sum"] = np.array(x_re.detach().double().sum().item())
+            out[f"s{step}.x_re_slice"] = x_re.detach()[:, :, 16].numpy()
+            out.update(sd_np(net.state_dict(), f"s{step}.sd."))
+    out["draw_seed"] = np.array(61)
+    np.savez_compressed(os.path.join(OUT, "g6_vae.npz"), **out)
+    print("g6_vae", len(out))
+
+
+# ---------------------------------------------------------------- G8 trainer
+class ListLoader:
+    """Minimal stand-in for a DataLoader: supports len() and iter()."""
+
+    def __init__(self, batches):
+        self.batches = batches
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def g8_train():
+    """The REAL reference train_soft_intro_vae: 2 epochs x 2 train batches + 1
+    val batch, B=8 (save_image indexes 8 images), 80x96x80 (hard-coded in the
+    trainer), narrow model."""
+    _stub_missing_modules()
+    import utils.my_trainer as T
+    import models.models as M
+    cfg = (2, [[2, 1, 2], [4, 1, 2], [4, 2, 2]])
+    torch.manual_seed(82)
+    net = M.SoftIntroVAE(*cfg)
+    gen = torch.Generator().manual_seed(108)
+    train = [(torch.rand(8, 1, 80, 96, 80, generator=gen), torch.zeros(8)) for _ in range(2)]
+    val = [(torch.rand(8, 1, 80, 96, 80, generator=gen), torch.zeros(8))]
+    out = {"cfg_in_ch": np.array(cfg[0]), "cfg_blocks": np.array(cfg[1]), "data_seed": np.array(108)}
+    draws = Draws(seed=81)
+    orig_randn = torch.randn
+    torch.randn = lambda *a, size=None, **k: draws.eps(size if size is not None else a[0] if isinstance(a[0], (tuple, list, torch.Size)) else a)
+    orig_apply = nn.Module.apply
+    captured = {}
+
+    def apply_and_capture(self, fn):
+        r = orig_apply(self, fn)
+        if self is net and "sd" not in captured:
+            captured["sd"] = sd_np(self.state_dict(), "sd0.")
+        return r
+
+    nn.Module.apply = apply_and_capture
+    with tempfile.TemporaryDirectory() as d:
+        for sub in ("imgs", "fakeimgs", "val_imgs", "prams", "test1"):
+            os.makedirs(os.path.join(d, sub))
+        try:
+            with patched_random(draws):
+                res = T.train_soft_intro_vae(net, ListLoader(train), ListLoader(val), 2, 2e-4,
+                                             torch.device("cpu"), d + "/", 1.0, 1024.0, 0.75)
+        finally:
+            torch.randn = orig_randn
+            nn.Module.apply = orig_apply
+        for name in ("loss.txt", "kl_losses.txt", "train_losses.txt", "val_losses.txt"):
+            with open(os.path.join(d, name)) as f:
+                out["txt." + name] = np.array(f.read())
+    out.update(captured["sd"])
+    for name, lst in zip(("train_lossE", "train_lossD", "val_lossE", "val_lossD"), res):
+        out["ret." + name] = np.array(lst, dtype=np.float64)
+    out.update(sd_np(net.state_dict(), "sd_final."))
+    out["draw_seed"] = np.array(81)
+    out["n_draws"] = np.array(draws.i)
+    np.savez_compressed(os.path.join(OUT, "g8_train.npz"), **out)
+    print("g8_train", {k: v for k, v in zip(("tE", "tD", "vE", "vD"), res)}, "draws", draws.i)
+
+
+ALL = {"g2": g2_blocks, "g3": g3_model, "g4": g4_step, "g5": g5_losses, "g6": g6_vae, "g8": g8_train}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    for k, fn in ALL.items():
+        if a.only is None or k in a.only:
+            fn()
