@@ -1,0 +1,166 @@
+/*
+ * libsiv -- MI355X (gfx950) kernels for the Soft-IntroVAE 3D-MRI training path.
+ *
+ * C ABI.  Plain pointers and sizes only; no torch types.  The reference
+ * (M-hayatooo/Soft-intro-VAE-for-3D-MRI) has no native code and no FFI: its
+ * "operator interface" for this path is the set of torch.nn / torch.nn.functional
+ * calls its model and trainer make.  Each entry point below names the reference
+ * call site(s) it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative SIV_E* code otherwise, never
+ *    throws and never exits; siv_last_error() returns a thread-local message.
+ *  - all tensors are caller-owned DEVICE pointers to fp32 unless stated.
+ *    Activations are NDHWC: [N][D][H][W][C] (the memory of a torch NCDHW tensor in
+ *    torch.channels_last_3d format).  3x3x3 weights are [Cout][kd][kh][kw][Cin]
+ *    (channels_last_3d memory of the reference's (Cout,Cin,3,3,3) parameter);
+ *    1x1x1 weights are [Cout][Cin].
+ *  - `stream` is a hipStream_t (0 = the null stream).  Every call is asynchronous
+ *    on that stream and performs no device synchronisation and no allocation.
+ *  - `ws`/`ws_bytes` is caller-provided scratch (device memory, 256-byte aligned);
+ *    siv_workspace_bytes() returns a size that is sufficient for every call.
+ *  - one stream at a time per workspace; calls are not re-entrant on one workspace.
+ */
+#ifndef SIV_H
+#define SIV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIV_OK 0
+#define SIV_EINVAL (-1)      /* bad argument (shape, null pointer, unsupported option) */
+#define SIV_EWORKSPACE (-2)  /* workspace too small */
+#define SIV_EHIP (-3)        /* a HIP runtime call or kernel launch failed */
+
+typedef void* siv_stream_t;  /* hipStream_t */
+
+const char* siv_last_error(void);
+int siv_version(void);
+/* Upper bound on the scratch any entry point needs for tensors up to the given size. */
+size_t siv_workspace_bytes(void);
+/* Kernel-path override for tests: 0 = automatic, 1 = force the generic (any-shape)
+ * kernels, 2 = force the specialised kernels (error when the shape has none). */
+int siv_set_conv_path(int path);
+
+/* ---- 3x3x3 convolution, stride 1, zero padding 1 --------------------------------
+ * Replaces nn.Conv3d(k=3,s=1,p=1) at models/models.py:17,21,55,59,92,137
+ * (models/vaemodel.py:16,20,53,57,88,128).  With ups == 2 the input is first
+ * nearest-upsampled x2, fusing nn.Upsample(scale_factor=2) of models/models.py:58:
+ * x is then [N][D/2][H/2][W/2][Cin].  D,H,W are always the OUTPUT extents.
+ * bias may be NULL. */
+int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bias, float* y,
+                      int N, int D, int H, int W, int Cin, int Cout, int ups,
+                      void* ws, size_t ws_bytes, siv_stream_t stream);
+/* Gradient w.r.t. the (non-upsampled) input of the same convolution: autograd of
+ * nn.Conv3d.  dx is [N][D][H][W][Cin]; dy is [N][D][H][W][Cout]. */
+int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx,
+                        int N, int D, int H, int W, int Cin, int Cout,
+                        void* ws, size_t ws_bytes, siv_stream_t stream);
+/* Gradient w.r.t. weight (and bias when dbias != NULL).  x as in _fwd (ups honoured).
+ * accumulate != 0 adds into dw/dbias instead of overwriting them. */
+int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, float* dbias,
+                        int N, int D, int H, int W, int Cin, int Cout, int ups, int accumulate,
+                        void* ws, size_t ws_bytes, siv_stream_t stream);
+/* Backward of nn.Upsample(scale_factor=2, nearest): dx[n][d][h][w][c] = sum of the
+ * 2x2x2 children of dy.  D,H,W are the extents of dy (even). */
+int siv_upsample2_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C,
+                      siv_stream_t stream);
+
+/* ---- 1x1x1 convolution (pointwise linear map over channels) ---------------------
+ * Replaces nn.Conv3d(k=1) at models/models.py:35,73 (shortcut projections), :118
+ * (decoder stem) and :216-217 (mu / var heads).  M = N*D*H*W rows. */
+int siv_conv1x1_fwd(const float* x, const float* w, const float* bias, float* y,
+                    long M, int Cin, int Cout, siv_stream_t stream);
+int siv_conv1x1_dgrad(const float* dy, const float* w, float* dx,
+                      long M, int Cin, int Cout, siv_stream_t stream);
+int siv_conv1x1_wgrad(const float* x, const float* dy, float* dw, float* dbias,
+                      long M, int Cin, int Cout, int accumulate,
+                      void* ws, size_t ws_bytes, siv_stream_t stream);
+
+/* ---- BatchNorm3d (+ residual + activation + AvgPool3d + Dropout) ----------------
+ * siv_bn_stats: training-mode batch statistics of nn.BatchNorm3d (models/models.py:18,22,
+ * 56,60,93,119): per-channel mean and BIASED variance over the M = N*D*H*W rows of y,
+ * and, when running_mean != NULL, the running-statistics update
+ *   running = (1-momentum)*running + momentum*stat   (unbiased variance, M/(M-1)),
+ *   num_batches_tracked += 1  (int64, may be NULL). */
+int siv_bn_stats(const float* y, long M, int C, float* mean, float* var,
+                 float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                 float momentum, void* ws, size_t ws_bytes, siv_stream_t stream);
+/* out = dropout( avgpool_k( act( gamma*(y-mean)/sqrt(var+eps)+beta [+ residual] ) ) )
+ *  - act: LeakyReLU(slope) (slope 0.2: models/models.py:15,19,94,121; slope 0: nn.ReLU of
+ *    models/vaemodel.py:14,18,90,113)
+ *  - pool: 1 or 2 = nn.AvgPool3d(kernel_size=stride) of models/models.py:20; out is then
+ *    [N][D/2][H/2][W/2][C]
+ *  - residual (NULL or [N][D][H][W][C]): the `+ shortcut` of models/models.py:41,78
+ *  - keep (NULL or uint8 0/1 per output element) and p: nn.Dropout(p) of models/models.py:95,122
+ *    in training mode, out *= keep/(1-p)
+ * Evaluation mode passes the running statistics as mean/var. */
+int siv_bn_act_fwd(const float* y, const float* mean, const float* var,
+                   const float* gamma, const float* beta, const float* residual,
+                   const uint8_t* keep, float p, float slope, int pool, float eps,
+                   float* out, int N, int D, int H, int W, int C, siv_stream_t stream);
+/* Backward of siv_bn_act_fwd in training mode (batch statistics take part in the
+ * gradient, as in autograd of nn.BatchNorm3d).  dy and dresidual may alias nothing;
+ * dgamma/dbeta/dresidual may be NULL.  accumulate != 0 adds into dgamma/dbeta. */
+int siv_bn_act_bwd(const float* dout, const float* y, const float* mean, const float* var,
+                   const float* gamma, const float* beta, const float* residual,
+                   const uint8_t* keep, float p, float slope, int pool, float eps,
+                   float* dy, float* dgamma, float* dbeta, float* dresidual, int accumulate,
+                   int N, int D, int H, int W, int C,
+                   void* ws, size_t ws_bytes, siv_stream_t stream);
+/* out = dropout(act(x)) without normalisation: the decoder tail nn.ReLU + nn.Dropout(0.35)
+ * of models/models.py:139-140, and its backward (dx = dout * keep/(1-p) * act'(x)). */
+int siv_act_dropout_fwd(const float* x, const uint8_t* keep, float p, float slope,
+                        float* out, long n, siv_stream_t stream);
+int siv_act_dropout_bwd(const float* dout, const float* x, const uint8_t* keep, float p,
+                        float slope, float* dx, long n, siv_stream_t stream);
+
+/* ---- latent sampling and losses -------------------------------------------------
+ * z = mu + eps*exp(0.5*logvar): SoftIntroVAE.reparameterize, models/models.py:263-271.
+ * eps == NULL uses the constant eps_const (0.1 in validation, models/models.py:269). */
+int siv_reparam_fwd(const float* mu, const float* logvar, const float* eps, float eps_const,
+                    float* z, long n, siv_stream_t stream);
+int siv_reparam_bwd(const float* dz, const float* logvar, const float* eps, float eps_const,
+                    float* dmu, float* dlogvar, long n, siv_stream_t stream);
+/* out[b] = -0.5 * sum_i (1 + logvar - mu^2 - exp(logvar)) over the n latent elements of
+ * sample b: calc_kl(reduce='none'), utils/my_trainer.py:38-48 (models/lossf.py:14-18). */
+int siv_kl_fwd(const float* mu, const float* logvar, float* out, int B, long n, siv_stream_t stream);
+/* dmu = g[b]*mu, dlogvar = g[b]*0.5*(exp(logvar)-1). */
+int siv_kl_bwd(const float* g, const float* mu, const float* logvar, float* dmu, float* dlogvar,
+               int B, long n, siv_stream_t stream);
+/* out[b] = sum_i (x-y)^2 over the n elements of sample b: calc_reconstruction_loss with
+ * reduction != 'mean', utils/my_trainer.py:62-78 (models/lossf.py:5-12). */
+int siv_sse_fwd(const float* x, const float* y, float* out, int B, long n,
+                void* ws, size_t ws_bytes, siv_stream_t stream);
+/* dx = 2 g[b] (x-y), dy = -dx; either output may be NULL. */
+int siv_sse_bwd(const float* g, const float* x, const float* y, float* dx, float* dy,
+                int B, long n, siv_stream_t stream);
+
+/* ---- optimiser -------------------------------------------------------------------
+ * One torch.optim.Adam step (lr, betas, eps; no weight decay, no amsgrad) over a flat
+ * parameter buffer: replaces optimizer_e.step()/optimizer_d.step(),
+ * utils/my_trainer.py:183-184,288,324.  `step` is the 1-based step count. */
+int siv_adam_step(float* p, const float* g, float* m, float* v, long n,
+                  float lr, float beta1, float beta2, float eps, int step, siv_stream_t stream);
+
+/* ---- device random numbers -------------------------------------------------------
+ * Philox-4x32-10 counter RNG keyed by (seed, stream_id); element i of a call uses
+ * counter i/4.  Replaces torch.randn / torch.randn_like (utils/my_trainer.py:238,
+ * models/models.py:266) and the Bernoulli draw inside nn.Dropout.
+ * keep[i] = 1 with probability 1-p. */
+int siv_randn(float* out, long n, uint64_t seed, uint64_t stream_id, siv_stream_t stream);
+int siv_dropout_keep(uint8_t* keep, long n, float p, uint64_t seed, uint64_t stream_id,
+                     siv_stream_t stream);
+
+/* ---- helpers ------------------------------------------------------------------------ */
+/* y = a*x + b*y elementwise (gradient accumulation / scaling on device). */
+int siv_axpby(float a, const float* x, float b, float* y, long n, siv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIV_H */

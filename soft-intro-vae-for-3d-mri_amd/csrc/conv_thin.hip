@@ -1,0 +1,337 @@
+// 3x3x3 convolutions with one channel on one side: the encoder stem (1 -> C), the decoder
+// output layer (C -> 1), their input gradients and their weight gradients.  These layers
+// move a full-resolution C-channel tensor exactly once and do little arithmetic: they are
+// HBM bound, so the kernels are organised around one coalesced pass over the wide tensor
+// with the single-channel side held as a halo brick in LDS.
+//
+//   one_to_c : out[v][c] = b[c] + sum_tap a[v+tap-1] * wk[c][tap]          (stem fwd, tail dgrad)
+//   c_to_one : out[v]    = b + sum_tap sum_c a[v+tap-1][c] * wk[tap][c]    (tail fwd, stem dgrad)
+//   thin_wg  : T[c][tap] = sum_u a[u+tap-1] * g[u][c]                      (both weight gradients)
+#include "siv_common.h"
+
+namespace siv {
+
+constexpr int TB_D = 4, TB_H = 8, TB_W = 8;           // output brick
+constexpr int TH_D = 6, TH_H = 10, TH_W = 10;         // halo brick
+constexpr int TB_V = TB_D * TB_H * TB_W;              // 256
+constexpr int TH_V = TH_D * TH_H * TH_W;              // 600
+
+__device__ __forceinline__ void brick_coords(int b, int nbd, int nbh, int nbw, int& n, int& z0,
+                                             int& y0, int& x0) {
+    const int bx = b % nbw; b /= nbw;
+    const int by = b % nbh; b /= nbh;
+    const int bz = b % nbd;
+    n = b / nbd;
+    z0 = bz * TB_D; y0 = by * TB_H; x0 = bx * TB_W;
+}
+
+// Load the single-channel halo brick (zero padded) into LDS.
+__device__ __forceinline__ void load_halo1(const float* __restrict__ a, float* hal, int n, int z0,
+                                           int y0, int x0, int D, int H, int W) {
+    for (int hv = threadIdx.x; hv < TH_V; hv += 256) {
+        const int hx = hv % TH_W, hy = (hv / TH_W) % TH_H, hz = hv / (TH_W * TH_H);
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        float v = 0.f;
+        if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            v = a[(((long)n * D + gz) * H + gy) * W + gx];
+        hal[hv] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// one_to_c.  Thread = (voxel lane, channel quad); the quad's 27x4 weights live in registers.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void one_to_c_k(const float* __restrict__ a,
+                                                  const float* __restrict__ w,
+                                                  const float* __restrict__ bias,
+                                                  float* __restrict__ out, int N, int D, int H, int W,
+                                                  int C, int flip, int nbd, int nbh, int nbw) {
+    __shared__ float hal[TH_V];
+    const int QC = C >> 2;
+    const int lanes = 256 / QC;
+    const int q = threadIdx.x % QC, vl = threadIdx.x / QC;
+    const bool active = vl < lanes;
+    float4 wr[27];
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            if (!flip) {  // w is [C][27][1]
+                wr[t] = make_float4(w[(4 * q + 0) * 27 + t], w[(4 * q + 1) * 27 + t],
+                                    w[(4 * q + 2) * 27 + t], w[(4 * q + 3) * 27 + t]);
+            } else {      // w is [1][27][C], taps reversed
+                wr[t] = *reinterpret_cast<const float4*>(w + (26 - t) * C + 4 * q);
+            }
+        }
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + 4 * q);
+    }
+    int n, z0, y0, x0;
+    brick_coords(blockIdx.x, nbd, nbh, nbw, n, z0, y0, x0);
+    load_halo1(a, hal, n, z0, y0, x0, D, H, W);
+    __syncthreads();
+    if (!active) return;
+    for (int m = vl; m < TB_V; m += lanes) {
+        const int dz = m >> 6, dy = (m >> 3) & 7, dx = m & 7;
+        const int gz = z0 + dz, gy = y0 + dy, gx = x0 + dx;
+        if (gz >= D || gy >= H || gx >= W) continue;
+        const float* hp = hal + (dz * TH_H + dy) * TH_W + dx;
+        float4 acc = bv;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const float av = hp[((t / 9) * TH_H + (t / 3) % 3) * TH_W + t % 3];
+            acc.x = fmaf(av, wr[t].x, acc.x);
+            acc.y = fmaf(av, wr[t].y, acc.y);
+            acc.z = fmaf(av, wr[t].z, acc.z);
+            acc.w = fmaf(av, wr[t].w, acc.w);
+        }
+        *reinterpret_cast<float4*>(out + ((((long)n * D + gz) * H + gy) * W + gx) * C + 4 * q) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// c_to_one.  Stage 1: p[u][tap] = <a[u][:], wk[tap][:]> for every halo voxel u, channels
+// streamed through LDS in chunks of 8 with each thread keeping the 27 running dots of its
+// voxels in registers.  Stage 2: out[v] = b + sum_tap p[v+tap-1][tap].
+// ---------------------------------------------------------------------------------
+constexpr int C1_CK = 8, C1_CKP = 12, C1_PP = 27;
+constexpr int C1_ROUNDS = (TH_V + 255) / 256;  // 3
+constexpr int C1_LDS_FLOATS = TH_V * C1_PP;    // p image; also covers the a chunk and weights
+static_assert(TH_V * C1_CKP + 27 * C1_CK <= C1_LDS_FLOATS, "LDS carve");
+
+__global__ __launch_bounds__(256) void c_to_one_k(const float* __restrict__ a,
+                                                  const float* __restrict__ w,
+                                                  const float* __restrict__ bias,
+                                                  float* __restrict__ out, int N, int D, int H, int W,
+                                                  int C, int flip, int nbd, int nbh, int nbw) {
+    __shared__ __attribute__((aligned(16))) float lds[C1_LDS_FLOATS];
+    float* ach = lds;                       // [600][12]
+    float* wch = lds + TH_V * C1_CKP;       // [27][8]
+    int n, z0, y0, x0;
+    brick_coords(blockIdx.x, nbd, nbh, nbw, n, z0, y0, x0);
+    float p[C1_ROUNDS][27];
+#pragma unroll
+    for (int r = 0; r < C1_ROUNDS; ++r)
+#pragma unroll
+        for (int t = 0; t < 27; ++t) p[r][t] = 0.f;
+
+    for (int c0 = 0; c0 < C; c0 += C1_CK) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < TH_V * 2; idx += 256) {
+            const int hv = idx >> 1, qq = idx & 1;
+            const int hx = hv % TH_W, hy = (hv / TH_W) % TH_H, hz = hv / (TH_W * TH_H);
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4*>(
+                    a + ((((long)n * D + gz) * H + gy) * W + gx) * C + c0 + 4 * qq);
+            *reinterpret_cast<float4*>(ach + hv * C1_CKP + 4 * qq) = v;
+        }
+        if (threadIdx.x < 27 * C1_CK) {
+            const int t = threadIdx.x / C1_CK, c = threadIdx.x % C1_CK;
+            wch[threadIdx.x] = flip ? w[(long)(c0 + c) * 27 + 26 - t] : w[(long)t * C + c0 + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < C1_ROUNDS; ++r) {
+            const int u = threadIdx.x + 256 * r;
+            if (u < TH_V) {
+                const float4 a0 = *reinterpret_cast<const float4*>(ach + u * C1_CKP);
+                const float4 a1 = *reinterpret_cast<const float4*>(ach + u * C1_CKP + 4);
+#pragma unroll
+                for (int t = 0; t < 27; ++t) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(wch + t * C1_CK);
+                    const float4 w1 = *reinterpret_cast<const float4*>(wch + t * C1_CK + 4);
+                    float s = p[r][t];
+                    s = fmaf(a0.x, w0.x, s); s = fmaf(a0.y, w0.y, s);
+                    s = fmaf(a0.z, w0.z, s); s = fmaf(a0.w, w0.w, s);
+                    s = fmaf(a1.x, w1.x, s); s = fmaf(a1.y, w1.y, s);
+                    s = fmaf(a1.z, w1.z, s); s = fmaf(a1.w, w1.w, s);
+                    p[r][t] = s;
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < C1_ROUNDS; ++r) {
+        const int u = threadIdx.x + 256 * r;
+        if (u < TH_V) {
+#pragma unroll
+            for (int t = 0; t < 27; ++t) lds[u * C1_PP + t] = p[r][t];
+        }
+    }
+    __syncthreads();
+    const int m = threadIdx.x;
+    const int dz = m >> 6, dy = (m >> 3) & 7, dx = m & 7;
+    const int gz = z0 + dz, gy = y0 + dy, gx = x0 + dx;
+    if (gz < D && gy < H && gx < W) {
+        float s = bias ? bias[0] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const int hv = ((dz + t / 9) * TH_H + dy + (t / 3) % 3) * TH_W + dx + t % 3;
+            s += lds[hv * C1_PP + t];
+        }
+        out[(((long)n * D + gz) * H + gy) * W + gx] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// thin_wg.  Thread = (voxel lane, channel quad) with 27 (+1 for the plain sum of g) float4
+// accumulators; every block walks a contiguous range of bricks, then the voxel lanes are
+// combined through LDS and one partial row per block is written: part[block][C][28].
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void thin_wg_k(const float* __restrict__ a,
+                                                 const float* __restrict__ g,
+                                                 float* __restrict__ part, int N, int D, int H, int W,
+                                                 int C, int nbd, int nbh, int nbw,
+                                                 int bricks_per_block) {
+    __shared__ float hal[TH_V];
+    __shared__ __attribute__((aligned(16))) float red[256 * 4];
+    const int QC = C >> 2;
+    const int lanes = 256 / QC;
+    const int q = threadIdx.x % QC, vl = threadIdx.x / QC;
+    const bool active = vl < lanes;
+    float4 acc[28];
+#pragma unroll
+    for (int t = 0; t < 28; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long nbricks = (long)N * nbd * nbh * nbw;
+    const long b0 = (long)blockIdx.x * bricks_per_block;
+    long b1 = b0 + bricks_per_block;
+    if (b1 > nbricks) b1 = nbricks;
+    for (long br = b0; br < b1; ++br) {
+        int n, z0, y0, x0;
+        brick_coords((int)br, nbd, nbh, nbw, n, z0, y0, x0);
+        __syncthreads();
+        load_halo1(a, hal, n, z0, y0, x0, D, H, W);
+        __syncthreads();
+        if (active) {
+            for (int m = vl; m < TB_V; m += lanes) {
+                const int dz = m >> 6, dy = (m >> 3) & 7, dx = m & 7;
+                const int gz = z0 + dz, gy = y0 + dy, gx = x0 + dx;
+                if (gz >= D || gy >= H || gx >= W) continue;
+                const float4 gv = *reinterpret_cast<const float4*>(
+                    g + ((((long)n * D + gz) * H + gy) * W + gx) * C + 4 * q);
+                const float* hp = hal + (dz * TH_H + dy) * TH_W + dx;
+#pragma unroll
+                for (int t = 0; t < 27; ++t) {
+                    const float av = hp[((t / 9) * TH_H + (t / 3) % 3) * TH_W + t % 3];
+                    acc[t].x = fmaf(av, gv.x, acc[t].x);
+                    acc[t].y = fmaf(av, gv.y, acc[t].y);
+                    acc[t].z = fmaf(av, gv.z, acc[t].z);
+                    acc[t].w = fmaf(av, gv.w, acc[t].w);
+                }
+                acc[27].x += gv.x; acc[27].y += gv.y; acc[27].z += gv.z; acc[27].w += gv.w;
+            }
+        }
+    }
+    // combine voxel lanes, tap by tap, in fixed order
+    float* pp = part + (long)blockIdx.x * C * 28;
+#pragma unroll
+    for (int t = 0; t < 28; ++t) {
+        __syncthreads();
+        *reinterpret_cast<float4*>(red + threadIdx.x * 4) = active ? acc[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        if (threadIdx.x < C) {
+            const int c = threadIdx.x;
+            float s = 0.f;
+            for (int l = 0; l < lanes; ++l) s += red[(l * QC + (c >> 2)) * 4 + (c & 3)];
+            pp[c * 28 + t] = s;
+        }
+    }
+}
+
+// mode 0 (stem): dw[c*27+tap] = T[c][tap], dbias[c] = T[c][27]
+// mode 1 (tail): dw[(26-tap)*C+c] = T[c][tap]
+__global__ __launch_bounds__(256) void thin_wg_reduce(const float* __restrict__ part, int nblk, int C,
+                                                      int mode, float* __restrict__ dw,
+                                                      float* __restrict__ dbias, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 28) return;
+    const int c = i / 28, t = i % 28;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(long)b * C * 28 + i];
+    float* dst = nullptr;
+    if (t < 27) dst = mode == 0 ? dw + c * 27 + t : dw + (26 - t) * C + c;
+    else if (mode == 0 && dbias) dst = dbias + c;
+    if (dst) *dst = accumulate ? *dst + (float)s : (float)s;
+}
+
+// sum of a flat array (gradient of the single-channel bias), two deterministic stages
+__global__ __launch_bounds__(256) void flat_sum_partial(const float* __restrict__ a, long n,
+                                                        float* __restrict__ part) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long)gridDim.x * blockDim.x)
+        acc += a[i];
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ void flat_sum_final(const float* __restrict__ part, int nblk, float* __restrict__ out,
+                               int accumulate) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += (double)part[b];
+        *out = accumulate ? *out + (float)s : (float)s;
+    }
+}
+
+bool k3_thin_supported(int Cin, int Cout) {
+    if (Cin == 1) return Cout % 4 == 0 && Cout >= 4 && Cout <= 256;
+    if (Cout == 1) return Cin % 8 == 0 && Cin >= 8 && Cin <= 256;
+    return false;
+}
+
+int k3_thin_fwd_launch(const float* a, const float* w, const float* bias, float* out, int N, int D,
+                       int H, int W, int Ca, int Cb, int flip, hipStream_t s) {
+    const int nbd = (D + TB_D - 1) / TB_D, nbh = (H + TB_H - 1) / TB_H, nbw = (W + TB_W - 1) / TB_W;
+    const long nblk = (long)N * nbd * nbh * nbw;
+    if (nblk > 0x7fffffffL) {
+        set_error("conv3d_k3(thin): too many bricks");
+        return SIV_EINVAL;
+    }
+    if (Ca == 1)
+        one_to_c_k<<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, Cb, flip, nbd, nbh, nbw);
+    else
+        c_to_one_k<<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, Ca, flip, nbd, nbh, nbw);
+    SIV_CHECK_LAUNCH("conv3d_k3(thin)");
+    return SIV_OK;
+}
+
+int k3_thin_wgrad_launch(const float* x, const float* dy, float* dw, float* dbias, int N, int D, int H,
+                         int W, int Cin, int Cout, int accumulate, void* ws, size_t ws_bytes,
+                         hipStream_t s) {
+    const int nbd = (D + TB_D - 1) / TB_D, nbh = (H + TB_H - 1) / TB_H, nbw = (W + TB_W - 1) / TB_W;
+    const long nbricks = (long)N * nbd * nbh * nbw;
+    const int mode = (Cin == 1) ? 0 : 1;
+    const int C = mode == 0 ? Cout : Cin;
+    if (C % 4 != 0 || C > 256) {
+        set_error("conv3d_k3_wgrad(thin): unsupported channel count %d", C);
+        return SIV_EINVAL;
+    }
+    long nblk = nbricks < 1024 ? nbricks : 1024;
+    const int bpb = (int)cdiv(nbricks, nblk);
+    nblk = cdiv(nbricks, bpb);
+    const size_t part_bytes = align256((size_t)nblk * C * 28 * sizeof(float));
+    SIV_CHECK_WS(part_bytes + 1024 * sizeof(float), ws_bytes, "conv3d_k3_wgrad(thin)");
+    float* part = (float*)ws;
+    const float* a = mode == 0 ? x : dy;
+    const float* g = mode == 0 ? dy : x;
+    thin_wg_k<<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb);
+    SIV_CHECK_LAUNCH("conv3d_k3_wgrad(thin)");
+    thin_wg_reduce<<<(C * 28 + 255) / 256, 256, 0, s>>>(part, (int)nblk, C, mode, dw, dbias, accumulate);
+    SIV_CHECK_LAUNCH("conv3d_k3_wgrad(thin reduce)");
+    if (mode == 1 && dbias) {
+        float* p2 = (float*)((char*)ws + part_bytes);
+        const long n = (long)N * D * H * W;
+        long gb = cdiv(n, 256 * 8);
+        if (gb > 1024) gb = 1024;
+        flat_sum_partial<<<(unsigned)gb, 256, 0, s>>>(dy, n, p2);
+        SIV_CHECK_LAUNCH("conv3d_k3_wgrad(thin bias)");
+        flat_sum_final<<<1, 64, 0, s>>>(p2, (int)gb, dbias, accumulate);
+        SIV_CHECK_LAUNCH("conv3d_k3_wgrad(thin bias final)");
+    }
+    return SIV_OK;
+}
+
+}  // namespace siv

@@ -1,0 +1,259 @@
+// Latent sampling, per-sample loss reductions, Adam, Philox RNG.  fp32, HBM/latency bound.
+#include "siv_common.h"
+
+namespace siv {
+
+static inline int ew_grid(long n) {
+    long g = cdiv(n, 256);
+    if (g > 256L * 16) g = 256L * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__global__ __launch_bounds__(256) void reparam_fwd_k(const float* __restrict__ mu,
+                                                     const float* __restrict__ logvar,
+                                                     const float* __restrict__ eps, float eps_const,
+                                                     float* __restrict__ z, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long)gridDim.x * blockDim.x) {
+        const float e = eps ? eps[i] : eps_const;
+        z[i] = fmaf(e, expf(0.5f * logvar[i]), mu[i]);
+    }
+}
+__global__ __launch_bounds__(256) void reparam_bwd_k(const float* __restrict__ dz,
+                                                     const float* __restrict__ logvar,
+                                                     const float* __restrict__ eps, float eps_const,
+                                                     float* __restrict__ dmu,
+                                                     float* __restrict__ dlogvar, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long)gridDim.x * blockDim.x) {
+        const float e = eps ? eps[i] : eps_const;
+        const float g = dz[i];
+        if (dmu) dmu[i] = g;
+        if (dlogvar) dlogvar[i] = g * e * 0.5f * expf(0.5f * logvar[i]);
+    }
+}
+
+// one block per sample
+__global__ __launch_bounds__(256) void kl_fwd_k(const float* __restrict__ mu,
+                                                const float* __restrict__ logvar,
+                                                float* __restrict__ out, long n) {
+    __shared__ float sh[4];
+    const long base = (long)blockIdx.x * n;
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+        const float m = mu[base + i], lv = logvar[base + i];
+        acc += 1.f + lv - m * m - expf(lv);
+    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = -0.5f * acc;
+}
+__global__ __launch_bounds__(256) void kl_bwd_k(const float* __restrict__ g,
+                                                const float* __restrict__ mu,
+                                                const float* __restrict__ logvar,
+                                                float* __restrict__ dmu, float* __restrict__ dlogvar,
+                                                int B, long n) {
+    const long total = (long)B * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const float gb = g[i / n];
+        dmu[i] = gb * mu[i];
+        dlogvar[i] = gb * 0.5f * (expf(logvar[i]) - 1.f);
+    }
+}
+
+// grid (chunks, B): partial[b][chunk]
+__global__ __launch_bounds__(256) void sse_partial_k(const float* __restrict__ x,
+                                                     const float* __restrict__ y,
+                                                     float* __restrict__ part, long n) {
+    __shared__ float sh[4];
+    const long base = (long)blockIdx.y * n;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long)gridDim.x * blockDim.x) {
+        const float d = x[base + i] - y[base + i];
+        acc = fmaf(d, d, acc);
+    }
+    acc = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) part[(long)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+}
+__global__ void sse_finalize_k(const float* __restrict__ part, int chunks, float* __restrict__ out,
+                               int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s = 0.0;
+    for (int i = 0; i < chunks; ++i) s += (double)part[(long)b * chunks + i];
+    out[b] = (float)s;
+}
+__global__ __launch_bounds__(256) void sse_bwd_k(const float* __restrict__ g,
+                                                 const float* __restrict__ x,
+                                                 const float* __restrict__ y, float* __restrict__ dx,
+                                                 float* __restrict__ dy, int B, long n) {
+    const long total = (long)B * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const float d = 2.f * g[i / n] * (x[i] - y[i]);
+        if (dx) dx[i] = d;
+        if (dy) dy[i] = -d;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float* __restrict__ g,
+                                              float* __restrict__ m, float* __restrict__ v, long n,
+                                              float b1, float b2, float eps, float step_size,
+                                              float inv_sqrt_bc2) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+__global__ __launch_bounds__(256) void axpby_k(float a, const float* __restrict__ x, float b,
+                                               float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long)gridDim.x * blockDim.x)
+        y[i] = (b == 0.f) ? a * x[i] : fmaf(a, x[i], b * y[i]);
+}
+
+// ---- Philox-4x32-10 ---------------------------------------------------------------
+struct u4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ u4 philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
+    uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
+    uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return u4{c0, c1, c2, c3};
+}
+__device__ __forceinline__ float u01(uint32_t r) {  // (0,1]
+    return ((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+__global__ __launch_bounds__(256) void randn_k(float* __restrict__ out, long n, uint64_t seed,
+                                               uint64_t sid) {
+    const long quads = (n + 3) / 4;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < quads;
+         q += (long)gridDim.x * blockDim.x) {
+        const u4 r = philox4x32_10((uint64_t)q, sid, seed);
+        const float r0 = sqrtf(-2.f * logf(u01(r.x))), t0 = 6.28318530717958647692f * u01(r.y);
+        const float r1 = sqrtf(-2.f * logf(u01(r.z))), t1 = 6.28318530717958647692f * u01(r.w);
+        const float v[4] = {r0 * cosf(t0), r0 * sinf(t0), r1 * cosf(t1), r1 * sinf(t1)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n) out[q * 4 + j] = v[j];
+    }
+}
+__global__ __launch_bounds__(256) void dropout_keep_k(uint8_t* __restrict__ keep, long n, float p,
+                                                      uint64_t seed, uint64_t sid) {
+    const long quads = (n + 3) / 4;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < quads;
+         q += (long)gridDim.x * blockDim.x) {
+        const u4 r = philox4x32_10((uint64_t)q, sid, seed);
+        const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n)
+                keep[q * 4 + j] = ((float)(rr[j] >> 8) * (1.0f / 16777216.0f)) >= p ? 1 : 0;
+    }
+}
+
+}  // namespace siv
+
+using namespace siv;
+
+extern "C" int siv_reparam_fwd(const float* mu, const float* logvar, const float* eps,
+                               float eps_const, float* z, long n, siv_stream_t stream) {
+    SIV_CHECK_ARG(mu && logvar && z && n > 0, "reparam_fwd: bad argument");
+    reparam_fwd_k<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(mu, logvar, eps, eps_const, z, n);
+    SIV_CHECK_LAUNCH("reparam_fwd");
+    return SIV_OK;
+}
+extern "C" int siv_reparam_bwd(const float* dz, const float* logvar, const float* eps,
+                               float eps_const, float* dmu, float* dlogvar, long n,
+                               siv_stream_t stream) {
+    SIV_CHECK_ARG(dz && logvar && n > 0, "reparam_bwd: bad argument");
+    reparam_bwd_k<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(dz, logvar, eps, eps_const, dmu,
+                                                               dlogvar, n);
+    SIV_CHECK_LAUNCH("reparam_bwd");
+    return SIV_OK;
+}
+extern "C" int siv_kl_fwd(const float* mu, const float* logvar, float* out, int B, long n,
+                          siv_stream_t stream) {
+    SIV_CHECK_ARG(mu && logvar && out && B > 0 && n > 0, "kl_fwd: bad argument");
+    kl_fwd_k<<<B, 256, 0, (hipStream_t)stream>>>(mu, logvar, out, n);
+    SIV_CHECK_LAUNCH("kl_fwd");
+    return SIV_OK;
+}
+extern "C" int siv_kl_bwd(const float* g, const float* mu, const float* logvar, float* dmu,
+                          float* dlogvar, int B, long n, siv_stream_t stream) {
+    SIV_CHECK_ARG(g && mu && logvar && dmu && dlogvar && B > 0 && n > 0, "kl_bwd: bad argument");
+    kl_bwd_k<<<ew_grid((long)B * n), 256, 0, (hipStream_t)stream>>>(g, mu, logvar, dmu, dlogvar, B, n);
+    SIV_CHECK_LAUNCH("kl_bwd");
+    return SIV_OK;
+}
+extern "C" int siv_sse_fwd(const float* x, const float* y, float* out, int B, long n, void* ws,
+                           size_t ws_bytes, siv_stream_t stream) {
+    SIV_CHECK_ARG(x && y && out && B > 0 && n > 0, "sse_fwd: bad argument");
+    long chunks = cdiv(n, 256 * 16);
+    if (chunks > 512) chunks = 512;
+    SIV_CHECK_WS((size_t)B * chunks * sizeof(float), ws_bytes, "sse_fwd");
+    hipStream_t s = (hipStream_t)stream;
+    sse_partial_k<<<dim3((unsigned)chunks, (unsigned)B), 256, 0, s>>>(x, y, (float*)ws, n);
+    SIV_CHECK_LAUNCH("sse_fwd(partial)");
+    sse_finalize_k<<<(B + 63) / 64, 64, 0, s>>>((const float*)ws, (int)chunks, out, B);
+    SIV_CHECK_LAUNCH("sse_fwd(finalize)");
+    return SIV_OK;
+}
+extern "C" int siv_sse_bwd(const float* g, const float* x, const float* y, float* dx, float* dy,
+                           int B, long n, siv_stream_t stream) {
+    SIV_CHECK_ARG(g && x && y && (dx || dy) && B > 0 && n > 0, "sse_bwd: bad argument");
+    sse_bwd_k<<<ew_grid((long)B * n), 256, 0, (hipStream_t)stream>>>(g, x, y, dx, dy, B, n);
+    SIV_CHECK_LAUNCH("sse_bwd");
+    return SIV_OK;
+}
+extern "C" int siv_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,
+                             float beta1, float beta2, float eps, int step, siv_stream_t stream) {
+    SIV_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_step: bad argument");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    adam_k<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, beta1, beta2, eps,
+                                                        (float)((double)lr / bc1),
+                                                        (float)(1.0 / sqrt(bc2)));
+    SIV_CHECK_LAUNCH("adam_step");
+    return SIV_OK;
+}
+extern "C" int siv_randn(float* out, long n, uint64_t seed, uint64_t stream_id, siv_stream_t stream) {
+    SIV_CHECK_ARG(out && n > 0, "randn: bad argument");
+    randn_k<<<ew_grid((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(out, n, seed, stream_id);
+    SIV_CHECK_LAUNCH("randn");
+    return SIV_OK;
+}
+extern "C" int siv_dropout_keep(uint8_t* keep, long n, float p, uint64_t seed, uint64_t stream_id,
+                                siv_stream_t stream) {
+    SIV_CHECK_ARG(keep && n > 0 && p >= 0.f && p < 1.f, "dropout_keep: bad argument");
+    dropout_keep_k<<<ew_grid((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(keep, n, p, seed, stream_id);
+    SIV_CHECK_LAUNCH("dropout_keep");
+    return SIV_OK;
+}
+extern "C" int siv_axpby(float a, const float* x, float b, float* y, long n, siv_stream_t stream) {
+    SIV_CHECK_ARG(x && y && n > 0, "axpby: bad argument");
+    axpby_k<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(a, x, b, y, n);
+    SIV_CHECK_LAUNCH("axpby");
+    return SIV_OK;
+}

@@ -1,0 +1,128 @@
+// C-ABI entry points that dispatch between the convolution kernel families, plus the
+// library-wide helpers (error string, version, workspace size, test overrides).
+#include "siv_common.h"
+#include <string.h>
+
+namespace siv {
+
+static thread_local char g_err[512] = "";
+static int g_conv_path = 0;
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int conv_path() { return g_conv_path; }
+
+// conv_generic.hip
+int k3_fwd_generic_launch(const float*, const float*, const float*, float*, int, int, int, int, int,
+                          int, int, hipStream_t);
+int k3_dgrad_generic_launch(const float*, const float*, float*, int, int, int, int, int, int,
+                            hipStream_t);
+int k3_wgrad_generic_launch(const float*, const float*, float*, float*, int, int, int, int, int, int,
+                            int, int, hipStream_t);
+int colsum_launch(const float*, float*, long, int, int, hipStream_t);
+// conv_mfma.hip
+bool k3_fwd_mfma_supported(int Cin, int Cout);
+int k3_fwd_mfma_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int,
+                       int, hipStream_t);
+int k3_flip_transpose_launch(const float*, float*, int, int, hipStream_t);
+bool k3_wgrad_mfma_supported(int Cin, int Cout);
+int k3_wgrad_mfma_launch(const float*, const float*, float*, int, int, int, int, int, int, int, int,
+                         void*, size_t, hipStream_t);
+// conv_thin.hip
+bool k3_thin_supported(int Cin, int Cout);
+int k3_thin_fwd_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int,
+                       int flip, hipStream_t);
+int k3_thin_wgrad_launch(const float*, const float*, float*, float*, int, int, int, int, int, int,
+                         int, void*, size_t, hipStream_t);
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static int check_conv_shape(const char* what, int N, int D, int H, int W, int Cin, int Cout, int ups) {
+    SIV_CHECK_ARG(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0,
+                  "%s: extents must be positive (N=%d D=%d H=%d W=%d Cin=%d Cout=%d)", what, N, D, H,
+                  W, Cin, Cout);
+    SIV_CHECK_ARG(ups == 1 || ups == 2, "%s: ups must be 1 or 2 (got %d)", what, ups);
+    SIV_CHECK_ARG(ups == 1 || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0),
+                  "%s: ups=2 needs even output extents (got %d,%d,%d)", what, D, H, W);
+    return SIV_OK;
+}
+
+}  // namespace siv
+
+using namespace siv;
+
+extern "C" const char* siv_last_error(void) { return g_err; }
+extern "C" int siv_version(void) { return 100; }
+extern "C" size_t siv_workspace_bytes(void) { return (size_t)512 << 20; }
+extern "C" int siv_set_conv_path(int path) {
+    SIV_CHECK_ARG(path >= 0 && path <= 2, "set_conv_path: path must be 0, 1 or 2");
+    g_conv_path = path;
+    return SIV_OK;
+}
+
+extern "C" int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bias, float* y, int N,
+                                 int D, int H, int W, int Cin, int Cout, int ups, void* ws,
+                                 size_t ws_bytes, siv_stream_t stream) {
+    (void)ws; (void)ws_bytes;
+    SIV_CHECK_ARG(x && w && y, "conv3d_k3_fwd: null pointer");
+    int rc = check_conv_shape("conv3d_k3_fwd", N, D, H, W, Cin, Cout, ups);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int path = conv_path();
+    const bool al = aligned16(x) && aligned16(w) && aligned16(y);
+    if (path != 1 && al && k3_fwd_mfma_supported(Cin, Cout))
+        return k3_fwd_mfma_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, s);
+    if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
+        return k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s);
+    SIV_CHECK_ARG(path != 2, "conv3d_k3_fwd: no specialised kernel for Cin=%d Cout=%d ups=%d", Cin,
+                  Cout, ups);
+    return k3_fwd_generic_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, s);
+}
+
+extern "C" int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx, int N, int D, int H,
+                                   int W, int Cin, int Cout, void* ws, size_t ws_bytes,
+                                   siv_stream_t stream) {
+    SIV_CHECK_ARG(dy && w && dx, "conv3d_k3_dgrad: null pointer");
+    int rc = check_conv_shape("conv3d_k3_dgrad", N, D, H, W, Cin, Cout, 1);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int path = conv_path();
+    const bool al = aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws);
+    // dgrad is the forward convolution of dy with the flipped, transposed weights
+    if (path != 1 && al && k3_fwd_mfma_supported(Cout, Cin)) {
+        SIV_CHECK_WS((size_t)Cout * 27 * Cin * sizeof(float), ws_bytes, "conv3d_k3_dgrad");
+        rc = k3_flip_transpose_launch(w, (float*)ws, Cin, Cout, s);
+        if (rc) return rc;
+        return k3_fwd_mfma_launch(dy, (const float*)ws, nullptr, dx, N, D, H, W, Cout, Cin, 1, s);
+    }
+    if (path != 1 && al && k3_thin_supported(Cout, Cin))
+        return k3_thin_fwd_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, s);
+    SIV_CHECK_ARG(path != 2, "conv3d_k3_dgrad: no specialised kernel for Cin=%d Cout=%d", Cin, Cout);
+    return k3_dgrad_generic_launch(dy, w, dx, N, D, H, W, Cin, Cout, s);
+}
+
+extern "C" int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N,
+                                   int D, int H, int W, int Cin, int Cout, int ups, int accumulate,
+                                   void* ws, size_t ws_bytes, siv_stream_t stream) {
+    SIV_CHECK_ARG(x && dy && dw, "conv3d_k3_wgrad: null pointer");
+    int rc = check_conv_shape("conv3d_k3_wgrad", N, D, H, W, Cin, Cout, ups);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int path = conv_path();
+    const bool al = aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(ws);
+    if (path != 1 && al && k3_wgrad_mfma_supported(Cin, Cout)) {
+        rc = k3_wgrad_mfma_launch(x, dy, dw, N, D, H, W, Cin, Cout, ups, accumulate, ws, ws_bytes, s);
+        if (rc) return rc;
+        if (dbias) return colsum_launch(dy, dbias, (long)N * D * H * W, Cout, accumulate, s);
+        return SIV_OK;
+    }
+    if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
+        return k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
+    SIV_CHECK_ARG(path != 2, "conv3d_k3_wgrad: no specialised kernel for Cin=%d Cout=%d ups=%d", Cin,
+                  Cout, ups);
+    return k3_wgrad_generic_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, ups, accumulate, s);
+}

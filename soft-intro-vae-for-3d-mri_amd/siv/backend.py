@@ -1,0 +1,311 @@
+"""Tensor-level view of the libsiv C ABI.
+
+``HipBackend`` turns torch tensors (logical NCDHW, ``channels_last_3d`` memory = NDHWC)
+into the raw pointers/extents the C entry points take, allocates outputs with torch's
+caching allocator and launches on torch's current HIP stream.  It is the only backend
+this package ships: there is no CPU path.  ``set_backend`` exists so that the test-suite
+can substitute a checker when exercising the host logic on a machine without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+CL3D = torch.channels_last_3d
+
+
+def cl(t: torch.Tensor) -> torch.Tensor:
+    """NDHWC memory for a logical NCDHW tensor (no copy when already so)."""
+    return t.contiguous(memory_format=CL3D)
+
+
+def empty_cl(shape, like: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    return torch.empty(tuple(shape), device=like.device, dtype=dtype, memory_format=CL3D)
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self._ws = {}
+
+    # ---- plumbing ------------------------------------------------------------
+    def _stream(self, t: torch.Tensor) -> int:
+        return torch.cuda.current_stream(t.device).cuda_stream
+
+    def _workspace(self, t: torch.Tensor) -> Tuple[int, int]:
+        dev = t.device
+        ws = self._ws.get(dev)
+        if ws is None:
+            nbytes = int(self.lib.siv_workspace_bytes())
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._ws[dev] = ws
+        return ws.data_ptr(), ws.numel()
+
+    @staticmethod
+    def _check_dev(*ts):
+        for t in ts:
+            if t is not None and not t.is_cuda:
+                raise _lib.SivError("libsiv kernels need tensors on a HIP device (got a CPU tensor); "
+                                    "there is no CPU fallback")
+            if t is not None and t.dtype not in (torch.float32, torch.uint8, torch.int64):
+                raise _lib.SivError(f"unsupported dtype {t.dtype}")
+
+    def set_conv_path(self, path: int) -> None:
+        _lib.check(self.lib.siv_set_conv_path(path), "siv_set_conv_path")
+
+    # ---- 3x3x3 convolution ------------------------------------------------------
+    def conv3d_k3_fwd(self, x, w, bias, ups: int = 1):
+        self._check_dev(x, w, bias)
+        x, w = cl(x), cl(w)
+        N, Cin, Di, Hi, Wi = x.shape
+        Cout = w.shape[0]
+        assert w.shape[1] == Cin and tuple(w.shape[2:]) == (3, 3, 3), (tuple(w.shape), Cin)
+        D, H, W = Di * ups, Hi * ups, Wi * ups
+        y = empty_cl((N, Cout, D, H, W), x)
+        ws, wsb = self._workspace(x)
+        _lib.check(self.lib.siv_conv3d_k3_fwd(_p(x), _p(w), _p(bias), _p(y), N, D, H, W, Cin, Cout, ups,
+                                              ws, wsb, self._stream(x)), "siv_conv3d_k3_fwd")
+        return y
+
+    def conv3d_k3_dgrad(self, dy, w, ups: int = 1):
+        self._check_dev(dy, w)
+        dy, w = cl(dy), cl(w)
+        N, Cout, D, H, W = dy.shape
+        Cin = w.shape[1]
+        dx = empty_cl((N, Cin, D, H, W), dy)
+        ws, wsb = self._workspace(dy)
+        st = self._stream(dy)
+        _lib.check(self.lib.siv_conv3d_k3_dgrad(_p(dy), _p(w), _p(dx), N, D, H, W, Cin, Cout, ws, wsb, st),
+                   "siv_conv3d_k3_dgrad")
+        if ups == 1:
+            return dx
+        assert ups == 2
+        dxs = empty_cl((N, Cin, D // 2, H // 2, W // 2), dy)
+        _lib.check(self.lib.siv_upsample2_bwd(_p(dx), _p(dxs), N, D, H, W, Cin, st), "siv_upsample2_bwd")
+        return dxs
+
+    def conv3d_k3_wgrad(self, x, dy, ups: int = 1, want_bias: bool = False):
+        self._check_dev(x, dy)
+        x, dy = cl(x), cl(dy)
+        N, Cout, D, H, W = dy.shape
+        Cin = x.shape[1]
+        dw = empty_cl((Cout, Cin, 3, 3, 3), dy)
+        db = torch.empty(Cout, device=dy.device, dtype=torch.float32) if want_bias else None
+        ws, wsb = self._workspace(dy)
+        _lib.check(self.lib.siv_conv3d_k3_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, D, H, W, Cin, Cout, ups, 0,
+                                                ws, wsb, self._stream(dy)), "siv_conv3d_k3_wgrad")
+        return dw, db
+
+    # ---- 1x1x1 convolution -------------------------------------------------------
+    def conv1x1_fwd(self, x, w, bias):
+        self._check_dev(x, w, bias)
+        x = cl(x)
+        w = w.contiguous()
+        N, Cin, D, H, W = x.shape
+        Cout = w.shape[0]
+        y = empty_cl((N, Cout, D, H, W), x)
+        _lib.check(self.lib.siv_conv1x1_fwd(_p(x), _p(w), _p(bias), _p(y), N * D * H * W, Cin, Cout,
+                                            self._stream(x)), "siv_conv1x1_fwd")
+        return y
+
+    def conv1x1_dgrad(self, dy, w):
+        self._check_dev(dy, w)
+        dy = cl(dy)
+        w = w.contiguous()
+        N, Cout, D, H, W = dy.shape
+        Cin = w.shape[1]
+        dx = empty_cl((N, Cin, D, H, W), dy)
+        _lib.check(self.lib.siv_conv1x1_dgrad(_p(dy), _p(w), _p(dx), N * D * H * W, Cin, Cout,
+                                              self._stream(dy)), "siv_conv1x1_dgrad")
+        return dx
+
+    def conv1x1_wgrad(self, x, dy, want_bias: bool = False):
+        self._check_dev(x, dy)
+        x, dy = cl(x), cl(dy)
+        N, Cout, D, H, W = dy.shape
+        Cin = x.shape[1]
+        dw = torch.empty((Cout, Cin, 1, 1, 1), device=dy.device, dtype=torch.float32)
+        db = torch.empty(Cout, device=dy.device, dtype=torch.float32) if want_bias else None
+        ws, wsb = self._workspace(dy)
+        _lib.check(self.lib.siv_conv1x1_wgrad(_p(x), _p(dy), _p(dw), _p(db), N * D * H * W, Cin, Cout, 0,
+                                              ws, wsb, self._stream(dy)), "siv_conv1x1_wgrad")
+        return dw, db
+
+    # ---- batch norm + activation tail --------------------------------------------
+    def bn_stats(self, y, running_mean, running_var, nbt, momentum: float):
+        self._check_dev(y, running_mean, running_var, nbt)
+        y = cl(y)
+        N, C, D, H, W = y.shape
+        mean = torch.empty(C, device=y.device, dtype=torch.float32)
+        var = torch.empty(C, device=y.device, dtype=torch.float32)
+        ws, wsb = self._workspace(y)
+        _lib.check(self.lib.siv_bn_stats(_p(y), N * D * H * W, C, _p(mean), _p(var), _p(running_mean),
+                                         _p(running_var), _p(nbt), float(momentum), ws, wsb,
+                                         self._stream(y)), "siv_bn_stats")
+        return mean, var
+
+    def bn_act_fwd(self, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps):
+        self._check_dev(y, mean, var, gamma, beta, res, keep)
+        y = cl(y)
+        res = cl(res) if res is not None else None
+        N, C, D, H, W = y.shape
+        out = empty_cl((N, C, D // pool, H // pool, W // pool), y)
+        if keep is not None:
+            keep = cl(keep)
+            assert keep.dtype == torch.uint8 and keep.shape == out.shape
+        _lib.check(self.lib.siv_bn_act_fwd(_p(y), _p(mean), _p(var), _p(gamma), _p(beta), _p(res), _p(keep),
+                                           float(p), float(slope), int(pool), float(eps), _p(out),
+                                           N, D, H, W, C, self._stream(y)), "siv_bn_act_fwd")
+        return out
+
+    def bn_act_bwd(self, dout, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps,
+                   want_affine: bool, want_res: bool):
+        self._check_dev(dout, y, mean, var, gamma, beta, res, keep)
+        dout, y = cl(dout), cl(y)
+        res = cl(res) if res is not None else None
+        keep = cl(keep) if keep is not None else None
+        N, C, D, H, W = y.shape
+        dy = torch.empty_like(y, memory_format=CL3D)
+        dgamma = torch.empty(C, device=y.device, dtype=torch.float32) if want_affine else None
+        dbeta = torch.empty(C, device=y.device, dtype=torch.float32) if want_affine else None
+        dres = torch.empty_like(y, memory_format=CL3D) if (want_res and res is not None) else None
+        ws, wsb = self._workspace(y)
+        _lib.check(self.lib.siv_bn_act_bwd(_p(dout), _p(y), _p(mean), _p(var), _p(gamma), _p(beta), _p(res),
+                                           _p(keep), float(p), float(slope), int(pool), float(eps),
+                                           _p(dy), _p(dgamma), _p(dbeta), _p(dres), 0, N, D, H, W, C,
+                                           ws, wsb, self._stream(y)), "siv_bn_act_bwd")
+        return dy, dgamma, dbeta, dres
+
+    def act_dropout_fwd(self, x, keep, p, slope):
+        self._check_dev(x, keep)
+        x = cl(x)
+        keep = cl(keep) if keep is not None else None
+        out = torch.empty_like(x, memory_format=CL3D)
+        _lib.check(self.lib.siv_act_dropout_fwd(_p(x), _p(keep), float(p), float(slope), _p(out), x.numel(),
+                                                self._stream(x)), "siv_act_dropout_fwd")
+        return out
+
+    def act_dropout_bwd(self, dout, x, keep, p, slope):
+        self._check_dev(dout, x, keep)
+        dout, x = cl(dout), cl(x)
+        keep = cl(keep) if keep is not None else None
+        dx = torch.empty_like(x, memory_format=CL3D)
+        _lib.check(self.lib.siv_act_dropout_bwd(_p(dout), _p(x), _p(keep), float(p), float(slope), _p(dx),
+                                                x.numel(), self._stream(x)), "siv_act_dropout_bwd")
+        return dx
+
+    # ---- latent sampling and losses ------------------------------------------------
+    def reparam_fwd(self, mu, logvar, eps, eps_const):
+        self._check_dev(mu, logvar, eps)
+        mu, logvar = cl(mu), cl(logvar)
+        eps = cl(eps) if eps is not None else None
+        z = torch.empty_like(mu, memory_format=CL3D)
+        _lib.check(self.lib.siv_reparam_fwd(_p(mu), _p(logvar), _p(eps), float(eps_const), _p(z), mu.numel(),
+                                            self._stream(mu)), "siv_reparam_fwd")
+        return z
+
+    def reparam_bwd(self, dz, logvar, eps, eps_const):
+        self._check_dev(dz, logvar, eps)
+        dz, logvar = cl(dz), cl(logvar)
+        eps = cl(eps) if eps is not None else None
+        dmu = torch.empty_like(dz, memory_format=CL3D)
+        dlv = torch.empty_like(dz, memory_format=CL3D)
+        _lib.check(self.lib.siv_reparam_bwd(_p(dz), _p(logvar), _p(eps), float(eps_const), _p(dmu), _p(dlv),
+                                            dz.numel(), self._stream(dz)), "siv_reparam_bwd")
+        return dmu, dlv
+
+    def kl_fwd(self, mu, logvar):
+        self._check_dev(mu, logvar)
+        mu, logvar = cl(mu), cl(logvar)
+        B = mu.shape[0]
+        out = torch.empty(B, device=mu.device, dtype=torch.float32)
+        _lib.check(self.lib.siv_kl_fwd(_p(mu), _p(logvar), _p(out), B, mu.numel() // B, self._stream(mu)),
+                   "siv_kl_fwd")
+        return out
+
+    def kl_bwd(self, g, mu, logvar):
+        self._check_dev(g, mu, logvar)
+        mu, logvar, g = cl(mu), cl(logvar), g.contiguous()
+        B = mu.shape[0]
+        dmu = torch.empty_like(mu, memory_format=CL3D)
+        dlv = torch.empty_like(mu, memory_format=CL3D)
+        _lib.check(self.lib.siv_kl_bwd(_p(g), _p(mu), _p(logvar), _p(dmu), _p(dlv), B, mu.numel() // B,
+                                       self._stream(mu)), "siv_kl_bwd")
+        return dmu, dlv
+
+    def sse_fwd(self, x, y):
+        self._check_dev(x, y)
+        x, y = cl(x), cl(y)
+        assert x.shape == y.shape, (x.shape, y.shape)
+        B = x.shape[0]
+        out = torch.empty(B, device=x.device, dtype=torch.float32)
+        ws, wsb = self._workspace(x)
+        _lib.check(self.lib.siv_sse_fwd(_p(x), _p(y), _p(out), B, x.numel() // B, ws, wsb, self._stream(x)),
+                   "siv_sse_fwd")
+        return out
+
+    def sse_bwd(self, g, x, y, want_x: bool, want_y: bool):
+        self._check_dev(g, x, y)
+        x, y, g = cl(x), cl(y), g.contiguous()
+        B = x.shape[0]
+        dx = torch.empty_like(x, memory_format=CL3D) if want_x else None
+        dy = torch.empty_like(x, memory_format=CL3D) if want_y else None
+        _lib.check(self.lib.siv_sse_bwd(_p(g), _p(x), _p(y), _p(dx), _p(dy), B, x.numel() // B,
+                                        self._stream(x)), "siv_sse_bwd")
+        return dx, dy
+
+    # ---- optimiser / rng / helpers ---------------------------------------------------
+    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step: int) -> None:
+        self._check_dev(p, g, m, v)
+        for t in (p, g, m, v):
+            assert t.is_contiguous() and t.dim() == 1 and t.numel() == p.numel()
+        _lib.check(self.lib.siv_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1),
+                                          float(beta2), float(eps), int(step), self._stream(p)),
+                   "siv_adam_step")
+
+    def randn(self, shape, device, seed: int, stream_id: int):
+        out = torch.empty(tuple(shape), device=device, dtype=torch.float32)
+        self._check_dev(out)
+        _lib.check(self.lib.siv_randn(_p(out), out.numel(), seed & (2 ** 64 - 1), stream_id & (2 ** 64 - 1),
+                                      self._stream(out)), "siv_randn")
+        return out
+
+    def dropout_keep(self, shape, device, p: float, seed: int, stream_id: int):
+        out = torch.empty(tuple(shape), device=device, dtype=torch.uint8, memory_format=CL3D)
+        self._check_dev(out)
+        _lib.check(self.lib.siv_dropout_keep(_p(out), out.numel(), float(p), seed & (2 ** 64 - 1),
+                                             stream_id & (2 ** 64 - 1), self._stream(out)),
+                   "siv_dropout_keep")
+        return out
+
+    def axpby(self, a: float, x, b: float, y) -> None:
+        self._check_dev(x, y)
+        assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+        _lib.check(self.lib.siv_axpby(float(a), _p(x), float(b), _p(y), x.numel(), self._stream(x)),
+                   "siv_axpby")
+
+
+_backend = None
+
+
+def get_backend():
+    """The HIP backend, created on first use.  Raises when libsiv.so is missing."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def set_backend(b) -> None:
+    """Install another backend object (test-suite hook); ``None`` restores the default."""
+    global _backend
+    _backend = b

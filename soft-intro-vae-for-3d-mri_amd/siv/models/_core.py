@@ -1,0 +1,287 @@
+"""3D ResNet encoder/decoder stacks whose forward and backward run in libsiv.
+
+Module tree, attribute names and ``state_dict`` keys are those of the reference
+(models/models.py and models/vaemodel.py): ``nn.Conv3d`` / ``nn.BatchNorm3d`` instances
+hold the parameters and buffers at the same positions inside the same ``nn.Sequential``
+containers, so reference checkpoints load both ways and ``model.apply(fn)`` with the
+reference's type checks (utils/my_trainer.py:511-519) behaves identically.  Their own
+``forward`` is never called: each block's ``forward`` drives the fused HIP operators
+(conv -> [BN + residual + activation + pool + dropout] as two launches per layer).
+
+A *variant* selects the activation slope and dropout rates:
+``SINTRO`` = models/models.py (LeakyReLU(0.2), Dropout .35/.25/.35),
+``PLAIN``  = models/vaemodel.py (ReLU, no dropout).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+
+from .. import ops, rng
+
+
+@dataclass(frozen=True)
+class Variant:
+    slope: float
+    p_enc_stem: float
+    p_dec_stem: float
+    p_dec_out: float
+
+
+SINTRO = Variant(0.2, 0.35, 0.25, 0.35)   # models/models.py:15,19,94-95,121-122,139-140
+PLAIN = Variant(0.0, 0.0, 0.0, 0.0)       # models/vaemodel.py:14,18,90,113,129
+
+
+def _act_module(v: Variant) -> nn.Module:
+    return nn.LeakyReLU(v.slope, inplace=True) if v.slope != 0.0 else nn.ReLU(inplace=True)
+
+
+def _keep(shape, p: float, training: bool, device):
+    if not training or p == 0.0:
+        return None
+    return rng.get_rng().keep_mask(shape, p, device)
+
+
+def _shortcut(in_ch: int, out_ch: int):
+    # models/models.py:28-35: identity, or a biased 1x1x1 projection when the widths differ
+    return nn.Conv3d(in_ch, out_ch, kernel_size=1, stride=1, padding=0) if in_ch != out_ch else None
+
+
+class _ResBlockBase(nn.Module):
+    """Shared by BuildingBlock / UpsampleBuildingkBlock: ``self.block`` is the reference's
+    six-entry Sequential (conv, BN, act, pool|upsample, conv, BN)."""
+
+    def _res(self, x):
+        if not self.res:
+            return None
+        sc = self._modules.get("shortcut")
+        return x if sc is None else ops.conv1x1(x, sc.weight, sc.bias)
+
+
+class BuildingBlock(_ResBlockBase):
+    """models/models.py:8-43.  conv3 -> BN -> act -> AvgPool(stride) -> conv3 -> BN ->
+    [+ shortcut(x) when stride == 1] -> act.  Stride-2 blocks never use their shortcut but
+    still own its parameters when in_ch != out_ch, as in the reference."""
+
+    def __init__(self, in_ch, out_ch, stride, bias=False, variant: Variant = SINTRO):
+        super().__init__()
+        self.res = stride == 1
+        self.stride = stride
+        self.variant = variant
+        sc = _shortcut(in_ch, out_ch)
+        if sc is not None:
+            self.shortcut = sc
+        self.block = nn.Sequential(
+            nn.Conv3d(in_ch, out_ch, kernel_size=3, stride=1, padding=1, bias=bias),
+            nn.BatchNorm3d(out_ch),
+            _act_module(variant),
+            nn.AvgPool3d(kernel_size=stride),
+            nn.Conv3d(out_ch, out_ch, kernel_size=3, stride=1, padding=1, bias=bias),
+            nn.BatchNorm3d(out_ch),
+        )
+
+    def forward(self, x):
+        c1, b1, _, _, c2, b2 = self.block
+        s = self.variant.slope
+        h = ops.conv3d_k3(x, c1.weight, c1.bias)
+        h = ops.bn_act(h, b1, s, pool=self.stride, train=self.training)
+        h = ops.conv3d_k3(h, c2.weight, c2.bias)
+        return ops.bn_act(h, b2, s, residual=self._res(x), train=self.training)
+
+
+class UpsampleBuildingkBlock(_ResBlockBase):
+    """models/models.py:46-80.  conv3(in->in) -> BN -> act -> nearest Upsample(stride) ->
+    conv3(in->out) -> BN -> [+ shortcut(x)] -> act.  The upsample is folded into the second
+    convolution's input gather; no upsampled tensor is materialised."""
+
+    def __init__(self, in_ch, out_ch, stride, bias=False, variant: Variant = SINTRO):
+        super().__init__()
+        self.res = stride == 1
+        self.stride = stride
+        self.variant = variant
+        sc = _shortcut(in_ch, out_ch)
+        if sc is not None:
+            self.shortcut = sc
+        self.block = nn.Sequential(
+            nn.Conv3d(in_ch, in_ch, kernel_size=3, stride=1, padding=1, bias=bias),
+            nn.BatchNorm3d(in_ch),
+            _act_module(variant),
+            nn.Upsample(scale_factor=stride),
+            nn.Conv3d(in_ch, out_ch, kernel_size=3, stride=1, padding=1, bias=bias),
+            nn.BatchNorm3d(out_ch),
+        )
+
+    def forward(self, x):
+        c1, b1, _, _, c2, b2 = self.block
+        s = self.variant.slope
+        if self.stride not in (1, 2):
+            raise ValueError(f"only stride 1 or 2 is supported (got {self.stride})")
+        h = ops.conv3d_k3(x, c1.weight, c1.bias)
+        h = ops.bn_act(h, b1, s, train=self.training)
+        h = ops.conv3d_k3(h, c2.weight, c2.bias, ups=self.stride)
+        return ops.bn_act(h, b2, s, residual=self._res(x), train=self.training)
+
+
+class ResNetEncoder(nn.Module):
+    """models/models.py:83-108: stem conv3(1->in_ch)+BN+act(+Dropout), BuildingBlock stack,
+    and the (unused by the VAE heads) ``conv`` 1x1x1 projection."""
+
+    def __init__(self, in_ch, block_setting, variant: Variant = SINTRO):
+        super().__init__()
+        self.block_setting = block_setting
+        self.in_ch = in_ch
+        self.variant = variant
+        stem = [nn.Conv3d(1, in_ch, kernel_size=3, stride=1, padding=1, bias=True),
+                nn.BatchNorm3d(in_ch), _act_module(variant)]
+        if variant.p_enc_stem > 0:
+            stem.append(nn.Dropout(p=variant.p_enc_stem))
+        blocks = [nn.Sequential(*stem)]
+        for c, n, s in block_setting:
+            for i in range(n):
+                blocks.append(nn.Sequential(BuildingBlock(in_ch, c, s if i == 0 else 1, variant=variant)))
+                in_ch = c
+        self.inner_ch = in_ch
+        self.blocks = nn.Sequential(*blocks)
+        self.conv = nn.Sequential(nn.Conv3d(in_ch, 1, kernel_size=1, stride=1, bias=True))
+
+    def features(self, x):
+        v = self.variant
+        conv, bn = self.blocks[0][0], self.blocks[0][1]
+        h = ops.conv3d_k3(x, conv.weight, conv.bias)
+        keep = _keep(h.shape, v.p_enc_stem, self.training, h.device)
+        h = ops.bn_act(h, bn, v.slope, keep=keep, p=v.p_enc_stem, train=self.training)
+        for blk in list(self.blocks)[1:]:
+            h = blk[0](h)
+        return h
+
+    def forward(self, x):
+        c = self.conv[0]
+        return ops.conv1x1(self.features(x), c.weight, c.bias)
+
+
+class VAEResNetEncoder(ResNetEncoder):
+    """models/models.py:213-223: two 1x1x1 heads ``mu`` and ``var`` (the latter is log-variance)."""
+
+    def __init__(self, in_ch, block_setting, variant: Variant = SINTRO):
+        super().__init__(in_ch, block_setting, variant)
+        self.mu = nn.Conv3d(self.inner_ch, 1, kernel_size=1, stride=1, bias=True)
+        self.var = nn.Conv3d(self.inner_ch, 1, kernel_size=1, stride=1, bias=True)
+
+    def forward(self, x):
+        h = self.features(x)
+        return ops.conv1x1(h, self.mu.weight, self.mu.bias), ops.conv1x1(h, self.var.weight, self.var.bias)
+
+
+class ResNetDecoder(nn.Module):
+    """models/models.py:110-145: 1x1x1 stem (1->last)+BN+act(+Dropout), mirrored upsample blocks,
+    conv3(in_ch->1)+ReLU(+Dropout)."""
+
+    def __init__(self, encoder: ResNetEncoder, blocks=None):
+        super().__init__()
+        v = self.variant = encoder.variant
+        setting = encoder.block_setting
+        last = setting[-1][0]
+        if blocks is None:
+            stem = [nn.Conv3d(1, last, 1, 1, bias=True), nn.BatchNorm3d(last), _act_module(v)]
+            if v.p_dec_stem > 0:
+                stem.append(nn.Dropout(p=v.p_dec_stem))
+            blocks = [nn.Sequential(*stem)]
+        in_ch = last
+        rev = setting[::-1]
+        for i, (c, n, s) in enumerate(rev):
+            nc = encoder.in_ch if i == len(rev) - 1 else rev[i + 1][0]
+            for j in range(n):
+                is_last = j == n - 1
+                out_ch = nc if is_last else c
+                blocks.append(nn.Sequential(
+                    UpsampleBuildingkBlock(in_ch, out_ch, s if is_last else 1, variant=v)))
+                in_ch = out_ch
+        tail = [nn.Conv3d(in_ch, 1, kernel_size=3, stride=1, padding=1, bias=True), nn.ReLU()]
+        if v.p_dec_out > 0:
+            tail.append(nn.Dropout(p=v.p_dec_out))
+        blocks.append(nn.Sequential(*tail))
+        self.blocks = nn.Sequential(*blocks)
+
+    def forward(self, z):
+        v = self.variant
+        mods = list(self.blocks)
+        conv, bn = mods[0][0], mods[0][1]
+        h = ops.conv1x1(z, conv.weight, conv.bias)
+        keep = _keep(h.shape, v.p_dec_stem, self.training, h.device)
+        h = ops.bn_act(h, bn, v.slope, keep=keep, p=v.p_dec_stem, train=self.training)
+        for blk in mods[1:-1]:
+            h = blk[0](h)
+        conv = mods[-1][0]
+        h = ops.conv3d_k3(h, conv.weight, conv.bias)
+        keep = _keep(h.shape, v.p_dec_out, self.training, h.device)
+        return ops.act_dropout(h, 0.0, keep=keep, p=v.p_dec_out)   # nn.ReLU then nn.Dropout
+
+
+def sample_eps(like: torch.Tensor) -> torch.Tensor:
+    """The ``torch.randn_like(std)`` of models/models.py:204,234,266."""
+    return rng.get_rng().eps(like.shape, like.device)
+
+
+class ResNetVAE(nn.Module):
+    """models/models.py:226-241 / models/vaemodel.py:215-230 (plus the BaseVAE helpers
+    :191-210): forward returns (x_re, mu, logvar)."""
+
+    variant = SINTRO
+
+    def __init__(self, in_ch, block_setting) -> None:
+        super().__init__()
+        self.encoder = VAEResNetEncoder(in_ch, block_setting, self.variant)
+        self.decoder = ResNetDecoder(self.encoder)
+
+    def encode(self, x):
+        return self.encoder(x)
+
+    def decode(self, vec):
+        return self.decoder(vec)
+
+    def reparameterize(self, mu, logvar):
+        return ops.reparameterize(mu, logvar, sample_eps(mu))
+
+    reparamenterize = reparameterize   # the reference's spelling, models/models.py:232
+
+    def forward(self, x):
+        mu, logvar = self.encoder(x)
+        z = self.reparameterize(mu, logvar)
+        return self.decoder(z), mu, logvar
+
+
+class SoftIntroVAE(nn.Module):
+    """models/models.py:257-285."""
+
+    variant = SINTRO
+
+    def __init__(self, in_ch, block_setting) -> None:
+        super().__init__()
+        self.encoder = VAEResNetEncoder(in_ch, block_setting, self.variant)
+        self.decoder = ResNetDecoder(self.encoder)
+
+    def reparameterize(self, mu, logvar, val_flag=False):
+        if val_flag is False:
+            return ops.reparameterize(mu, logvar, sample_eps(mu))
+        return ops.reparameterize(mu, logvar, None, 0.1)      # eps = 0.1, models/models.py:269
+
+    def forward(self, x):
+        mu, logvar = self.encoder(x)
+        z = self.reparameterize(mu, logvar)
+        return mu, logvar, z, self.decoder(z)
+
+    def encode(self, x, o_cond=None):
+        return self.encoder(x)
+
+    def decode(self, z, y_cond=None):
+        return self.decoder(z)
+
+    def latent_shape(self, batch: int, dims):
+        """Shape of the conv latent for input extents ``dims`` (the reference hard-codes
+        (B,1,10,12,10) for 80x96x80, utils/my_trainer.py:238)."""
+        f = 1
+        for _, _, s in self.encoder.block_setting:
+            f *= s
+        return (batch, 1) + tuple(d // f for d in dims)

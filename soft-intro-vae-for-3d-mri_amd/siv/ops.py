@@ -1,0 +1,182 @@
+"""Differentiable operators of the training path: torch.autograd.Function wrappers whose
+forward and backward both run in libsiv.  autograd supplies only the bookkeeping (which
+backward passes run is decided by ``requires_grad`` / ``detach`` exactly as in the
+reference trainer)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from .backend import get_backend
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class _Conv3dK3(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, ups):
+        ctx.save_for_backward(x, w)
+        ctx.ups = ups
+        ctx.has_bias = bias is not None
+        return get_backend().conv3d_k3_fwd(x, w, bias, ups)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B = get_backend()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = B.conv3d_k3_dgrad(dy, w, ctx.ups)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            dw, db = B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b)
+            if not ctx.needs_input_grad[1]:
+                dw = None
+        return dx, dw, db, None
+
+
+def conv3d_k3(x, w, bias=None, ups: int = 1):
+    """nn.Conv3d(k=3, s=1, p=1), optionally fused with a preceding nearest x2 upsample."""
+    return _Conv3dK3.apply(x, w, bias, ups)
+
+
+class _Conv1x1(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return get_backend().conv1x1_fwd(x, w, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B = get_backend()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = B.conv1x1_dgrad(dy, w)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            dw, db = B.conv1x1_wgrad(x, dy, want_b)
+            if not ctx.needs_input_grad[1]:
+                dw = None
+        return dx, dw, db
+
+
+def conv1x1(x, w, bias=None):
+    """nn.Conv3d(kernel_size=1)."""
+    return _Conv1x1.apply(x, w, bias)
+
+
+class _BnAct(Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, res, keep, bn, p, slope, pool, train):
+        B = get_backend()
+        if train:
+            mean, var = B.bn_stats(y, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                   BN_MOMENTUM if bn.momentum is None else bn.momentum)
+        else:
+            mean, var = bn.running_mean, bn.running_var
+        out = B.bn_act_fwd(y, mean, var, gamma, beta, res, keep, p, slope, pool, bn.eps)
+        ctx.save_for_backward(y, mean, var, gamma, beta, res, keep)
+        ctx.cfg = (p, slope, pool, bn.eps, train)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, mean, var, gamma, beta, res, keep = ctx.saved_tensors
+        p, slope, pool, eps, train = ctx.cfg
+        if not train:
+            raise NotImplementedError("backward through evaluation-mode BatchNorm is not part of the "
+                                      "training path (the reference validates under torch.no_grad())")
+        want_aff = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        want_res = res is not None and ctx.needs_input_grad[3]
+        dy, dg, db, dres = get_backend().bn_act_bwd(dout, y, mean, var, gamma, beta, res, keep, p, slope,
+                                                    pool, eps, want_aff, want_res)
+        if not ctx.needs_input_grad[0]:
+            dy = None
+        return (dy, dg if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None,
+                dres, None, None, None, None, None, None)
+
+
+def bn_act(y, bn, slope: float, pool: int = 1, residual=None, keep=None, p: float = 0.0,
+           train: bool = True):
+    """BatchNorm3d (parameters/buffers of module ``bn``) -> [+residual] -> LeakyReLU(slope)
+    -> AvgPool3d(pool) -> dropout(keep, p) as one fused pass."""
+    if pool not in (1, 2):
+        raise ValueError(f"only stride/pool 1 or 2 is supported (got {pool})")
+    return _BnAct.apply(y, bn.weight, bn.bias, residual, keep, bn, p, slope, pool, train)
+
+
+class _ActDropout(Function):
+    @staticmethod
+    def forward(ctx, x, keep, p, slope):
+        ctx.save_for_backward(x, keep)
+        ctx.cfg = (p, slope)
+        return get_backend().act_dropout_fwd(x, keep, p, slope)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, keep = ctx.saved_tensors
+        p, slope = ctx.cfg
+        return get_backend().act_dropout_bwd(dout, x, keep, p, slope), None, None, None
+
+
+def act_dropout(x, slope: float, keep=None, p: float = 0.0):
+    """LeakyReLU(slope) (slope 0 = ReLU) followed by dropout with an explicit keep mask."""
+    return _ActDropout.apply(x, keep, p, slope)
+
+
+class _Reparam(Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, eps, eps_const):
+        ctx.save_for_backward(logvar, eps)
+        ctx.eps_const = eps_const
+        return get_backend().reparam_fwd(mu, logvar, eps, eps_const)
+
+    @staticmethod
+    def backward(ctx, dz):
+        logvar, eps = ctx.saved_tensors
+        dmu, dlv = get_backend().reparam_bwd(dz, logvar, eps, ctx.eps_const)
+        return dmu, dlv, None, None
+
+
+def reparameterize(mu, logvar, eps: Optional[torch.Tensor], eps_const: float = 0.0):
+    """z = mu + eps * exp(0.5 * logvar); ``eps=None`` uses the constant ``eps_const``."""
+    return _Reparam.apply(mu, logvar, eps, eps_const)
+
+
+class _KlPerSample(Function):
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        ctx.save_for_backward(mu, logvar)
+        return get_backend().kl_fwd(mu, logvar)
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, logvar = ctx.saved_tensors
+        return get_backend().kl_bwd(g, mu, logvar)
+
+
+def kl_per_sample(mu, logvar):
+    """(B,) vector of -0.5 * sum(1 + logvar - mu^2 - exp(logvar)) per sample."""
+    return _KlPerSample.apply(mu, logvar)
+
+
+class _SsePerSample(Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        ctx.save_for_backward(x, y)
+        return get_backend().sse_fwd(x, y)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        return get_backend().sse_bwd(g, x, y, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+
+
+def sse_per_sample(x, y):
+    """(B,) vector of sum((x - y)^2) per sample."""
+    return _SsePerSample.apply(x, y)

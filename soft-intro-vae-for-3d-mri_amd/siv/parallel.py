@@ -1,0 +1,73 @@
+"""Data parallelism: one process per GPU, replicated weights, RCCL all-reduce of the flat
+encoder / decoder gradient buffers.
+
+Replaces the reference's single-process ``torch.nn.DataParallel(model, device_ids=[2, 3])``
+(main_DataParallel.py:609).  Semantics kept from DataParallel: the global batch is split on
+dim 0, BatchNorm statistics are per replica (no SyncBN), every loss term is a batch mean so
+the average of the rank gradients equals the full-batch gradient.  Each optimiser step
+needs exactly one exchange: sum the rank gradients, divide by the world size.
+
+The all-reduce runs on a side HIP stream so that the (tiny, 28.5 MB) exchange of one
+buffer can overlap whatever the main stream still has queued; the optimiser waits on an
+event, never on the host.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+from .backend import get_backend
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), \
+        int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_process_group(backend: str = None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
+    'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+class GradSync:
+    """Averages a flat gradient buffer over all ranks."""
+
+    def __init__(self, device=None):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.side = None
+        if self.world > 1 and device is not None and torch.device(device).type == "cuda":
+            self.side = torch.cuda.Stream(device=device)
+
+    def shard(self, batch: torch.Tensor) -> torch.Tensor:
+        """Rank r's slice [r*B/W, (r+1)*B/W) of a global batch."""
+        if self.world == 1:
+            return batch
+        b = batch.shape[0]
+        if b % self.world:
+            raise ValueError(f"global batch {b} is not divisible by world size {self.world}")
+        per = b // self.world
+        return batch[self.rank * per:(self.rank + 1) * per]
+
+    def average_(self, flat_g: torch.Tensor) -> None:
+        if self.world == 1:
+            return
+        if self.side is not None:
+            main = torch.cuda.current_stream(flat_g.device)
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
+            main.wait_stream(self.side)
+        else:
+            dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
+        get_backend().axpby(1.0 / self.world, flat_g, 0.0, flat_g)

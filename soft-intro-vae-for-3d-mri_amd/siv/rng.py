@@ -1,0 +1,80 @@
+"""Random draws of the training path.
+
+The reference draws from torch's global generator in three places: the latent noise
+(utils/my_trainer.py:238), the ``eps`` of the reparameterisation (models/models.py:266)
+and the Bernoulli masks inside nn.Dropout (models/models.py:95,122,140).  Here every
+draw goes through one object so that
+
+* production runs use the device Philox generator of libsiv, keyed by
+  (seed, rank, running call index) -- no host round trip, no mask tensor on the host;
+* parity tests can replay explicit tensors into the very same call sites.
+"""
+from __future__ import annotations
+
+import contextlib
+
+import torch
+
+from .backend import get_backend
+
+
+class DeviceRng:
+    """Philox-4x32-10 on the device; call ``i`` of rank ``r`` uses stream id (r << 40) | i."""
+
+    def __init__(self, seed: int = 0, rank: int = 0):
+        self.seed = int(seed)
+        self.rank = int(rank)
+        self.calls = 0
+
+    def _sid(self) -> int:
+        sid = (self.rank << 40) | self.calls
+        self.calls += 1
+        return sid
+
+    def keep_mask(self, shape, p: float, device) -> torch.Tensor:
+        return get_backend().dropout_keep(shape, device, p, self.seed, self._sid())
+
+    def eps(self, shape, device) -> torch.Tensor:
+        return get_backend().randn(shape, device, self.seed, self._sid())
+
+
+class ReplayRng:
+    """Hands out explicit tensors from ``source`` (anything with ``mask(shape, p)`` and
+    ``eps(shape)`` returning CPU float tensors), moved to the requested device."""
+
+    def __init__(self, source):
+        self.source = source
+
+    def keep_mask(self, shape, p: float, device) -> torch.Tensor:
+        m = self.source.mask(tuple(shape), p)
+        return m.to(torch.uint8).to(device).contiguous(memory_format=torch.channels_last_3d)
+
+    def eps(self, shape, device) -> torch.Tensor:
+        return self.source.eps(tuple(shape)).to(device)
+
+
+_current = DeviceRng(0)
+
+
+def get_rng():
+    return _current
+
+
+def set_rng(r) -> None:
+    global _current
+    _current = r
+
+
+def manual_seed(seed: int, rank: int = 0) -> None:
+    set_rng(DeviceRng(seed, rank))
+
+
+@contextlib.contextmanager
+def use_rng(r):
+    global _current
+    prev = _current
+    _current = r
+    try:
+        yield r
+    finally:
+        _current = prev

@@ -1,0 +1,135 @@
+"""TEST-ONLY stand-in for siv.backend.HipBackend that computes every operator on the CPU
+with plain torch / oracle code.  It lets the CPU test-suite exercise the HOST logic of the
+product (autograd wiring, trainer bookkeeping, flat optimiser, gradient averaging) against
+the reference goldens on a machine without a GPU.  It is never importable from the product
+package and nothing in ``siv`` falls back to it."""
+import torch
+import torch.nn.functional as F
+from torch.nn import grad as nngrad
+
+from oracle import siv_oracle as O
+
+
+class CpuCheckerBackend:
+    name = "cpu-checker"
+
+    def set_conv_path(self, path):
+        pass
+
+    def conv3d_k3_fwd(self, x, w, bias, ups=1):
+        return O.conv3d_k3(x, w, bias, ups)
+
+    def conv3d_k3_dgrad(self, dy, w, ups=1):
+        N, Cout, D, H, W = dy.shape
+        dx = nngrad.conv3d_input((N, w.shape[1], D, H, W), w, dy, stride=1, padding=1)
+        if ups != 1:
+            dx = F.avg_pool3d(dx, ups) * (ups ** 3)
+        return dx
+
+    def conv3d_k3_wgrad(self, x, dy, ups=1, want_bias=False):
+        if ups != 1:
+            x = F.interpolate(x, scale_factor=ups, mode="nearest")
+        dw = nngrad.conv3d_weight(x, (dy.shape[1], x.shape[1], 3, 3, 3), dy, stride=1, padding=1)
+        return dw, (dy.sum(dim=(0, 2, 3, 4)) if want_bias else None)
+
+    def conv1x1_fwd(self, x, w, bias):
+        return F.conv3d(x, w, bias)
+
+    def conv1x1_dgrad(self, dy, w):
+        return nngrad.conv3d_input((dy.shape[0], w.shape[1]) + tuple(dy.shape[2:]), w, dy)
+
+    def conv1x1_wgrad(self, x, dy, want_bias=False):
+        dw = nngrad.conv3d_weight(x, (dy.shape[1], x.shape[1], 1, 1, 1), dy)
+        return dw, (dy.sum(dim=(0, 2, 3, 4)) if want_bias else None)
+
+    def bn_stats(self, y, running_mean, running_var, nbt, momentum):
+        mean = y.mean(dim=(0, 2, 3, 4))
+        var = y.var(dim=(0, 2, 3, 4), unbiased=False)
+        if running_mean is not None:
+            m = y.numel() // y.shape[1]
+            running_mean.mul_(1 - momentum).add_(momentum * mean)
+            running_var.mul_(1 - momentum).add_(momentum * var * (m / max(m - 1, 1)))
+        if nbt is not None:
+            nbt += 1
+        return mean, var
+
+    @staticmethod
+    def _tail(y, mean, var, gamma, beta, res, keep, p, slope, pool, eps):
+        sh = (1, -1, 1, 1, 1)
+        h = (y - mean.view(sh)) / torch.sqrt(var.view(sh) + eps) * gamma.view(sh) + beta.view(sh)
+        if res is not None:
+            h = h + res
+        h = O.act(h, slope)
+        if pool != 1:
+            h = F.avg_pool3d(h, pool)
+        if keep is not None:
+            h = h * keep.float() * (1.0 / (1.0 - p))
+        return h
+
+    def bn_act_fwd(self, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps):
+        return self._tail(y, mean, var, gamma, beta, res, keep, p, slope, pool, eps)
+
+    def bn_act_bwd(self, dout, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps, want_affine, want_res):
+        # differentiate THROUGH the batch statistics, as training-mode BatchNorm does
+        with torch.enable_grad():
+            yy = y.detach().requires_grad_(True)
+            g = gamma.detach().requires_grad_(True)
+            b = beta.detach().requires_grad_(True)
+            r = res.detach().requires_grad_(True) if res is not None else None
+            m = yy.mean(dim=(0, 2, 3, 4))
+            v = yy.var(dim=(0, 2, 3, 4), unbiased=False)
+            out = self._tail(yy, m, v, g, b, r, keep, p, slope, pool, eps)
+            ins = [yy, g, b] + ([r] if r is not None else [])
+            grads = torch.autograd.grad(out, ins, dout)
+        dres = grads[3] if (r is not None and want_res) else None
+        return grads[0], (grads[1] if want_affine else None), (grads[2] if want_affine else None), dres
+
+    def act_dropout_fwd(self, x, keep, p, slope):
+        h = O.act(x, slope)
+        return h * keep.float() * (1.0 / (1.0 - p)) if keep is not None else h
+
+    def act_dropout_bwd(self, dout, x, keep, p, slope):
+        g = dout * keep.float() * (1.0 / (1.0 - p)) if keep is not None else dout
+        return g * torch.where(x > 0, torch.ones_like(x), torch.full_like(x, slope))
+
+    def reparam_fwd(self, mu, logvar, eps, eps_const):
+        e = eps if eps is not None else eps_const
+        return mu + e * torch.exp(0.5 * logvar)
+
+    def reparam_bwd(self, dz, logvar, eps, eps_const):
+        e = eps if eps is not None else eps_const
+        return dz, dz * e * 0.5 * torch.exp(0.5 * logvar)
+
+    def kl_fwd(self, mu, logvar):
+        return O.calc_kl(logvar, mu, "none")
+
+    def kl_bwd(self, g, mu, logvar):
+        gb = g.view(-1, *([1] * (mu.dim() - 1)))
+        return gb * mu, gb * 0.5 * (logvar.exp() - 1)
+
+    def sse_fwd(self, x, y):
+        return O.calc_reconstruction_loss(x, y, "none")
+
+    def sse_bwd(self, g, x, y, want_x, want_y):
+        d = 2 * g.view(-1, *([1] * (x.dim() - 1))) * (x - y)
+        return (d if want_x else None), (-d if want_y else None)
+
+    def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step):
+        st = {0: {"step": step - 1, "m": m, "v": v}}
+        with torch.no_grad():
+            O.adam_step([p], [g], st, lr, beta1, beta2, eps)
+
+    def randn(self, shape, device, seed, stream_id):
+        gen = torch.Generator().manual_seed((seed * 7919 + stream_id) % (2 ** 63))
+        return torch.randn(tuple(shape), generator=gen)
+
+    def dropout_keep(self, shape, device, p, seed, stream_id):
+        gen = torch.Generator().manual_seed((seed * 7919 + stream_id) % (2 ** 63))
+        return (torch.rand(tuple(shape), generator=gen) >= p).to(torch.uint8)
+
+    def axpby(self, a, x, b, y):
+        with torch.no_grad():
+            if b == 0.0:
+                y.copy_(a * x)
+            else:
+                y.mul_(b).add_(x, alpha=a)
