@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the Soft-IntroVAE training step (E-step + D-step, both Adam updates) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full iteration of utils/my_trainer.py:242-325 on one batch of synthetic volumes
+that is already resident in HBM.  Workload: BASELINE.json configs[2] -- 80x96x80 fp32, z=1200,
+SoftIntroVAE(64,[[64,1,2],[128,1,2],[256,2,2]]), batch 8 per GPU (weak scaling: global batch
+8*N, rank gradients averaged with RCCL all-reduce before each optimiser step).
+
+Rank 0 prints ONE JSON line: volumes/s over all GPUs, the roofline of the dominant kernel
+(measured live with HIP events on the launch stream inside the timed region) and, at N=1, the
+CPU oracle timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "soft-intro-vae-for-3d-mri_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MODEL = (64, [[64, 1, 2], [128, 1, 2], [256, 2, 2]])     # z-1200main.py:158
+DIMS = (80, 96, 80)
+PER_GPU_BATCH = 8
+FP32_PEAK_TFLOPS = 157.3                                   # MI355X fp32 matrix/vector peak
+# dominant kernel: 3x3x3 conv 64->64 at 80x96x80 (60 % of the model's FLOPs):
+# 2 * 27 * 64 * 64 * 614400 = 135.9 GFLOP per volume per launch
+DOM_FLOP_PER_VOLUME = 2.0 * 27 * 64 * 64 * DIMS[0] * DIMS[1] * DIMS[2]
+
+
+def build_model(device):
+    import siv.models.models as models
+    import siv.utils.my_trainer as trainer
+    torch.manual_seed(82)                                  # z-1200main.py:152
+    net = models.SoftIntroVAE(*MODEL)
+    torch.manual_seed(77)                                  # utils/my_trainer.py:160-171
+    net.apply(trainer.init_weights_he)
+    return net.to(device).train()
+
+
+def cpu_baseline(budget_s=25.0):
+    """The CPU oracle (a port: plain torch fp32 on the host cores) on a bounded sample of the same
+    workload: ONE volume through encoder+decoder forward and backward (6 of the 32 network passes of
+    a full step), extrapolated to a full step by the pass count."""
+    from oracle import siv_oracle as O
+    import siv.models.models as models
+    import siv.utils.my_trainer as trainer
+    cores = os.cpu_count() or 1
+    threads = min(cores, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    torch.manual_seed(82)
+    net = models.SoftIntroVAE(*MODEL)
+    torch.manual_seed(77)
+    net.apply(trainer.init_weights_he)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    cfg = O.Cfg(*MODEL)
+    x = torch.rand(1, 1, *DIMS, generator=torch.Generator().manual_seed(103))
+    keys = O.param_keys(sd, "encoder.") + O.param_keys(sd, "decoder.")
+    times = []
+    t_start = time.time()
+    for it in range(3):
+        for k in keys:
+            sd[k] = sd[k].detach().requires_grad_(True)
+        t0 = time.time()
+        mu, logvar, z, x_re = O.forward(x, sd, cfg, O.Draws(seed=it), True)
+        loss = O.calc_reconstruction_loss(x, x_re, "mean") + O.calc_kl(logvar, mu, "mean")
+        torch.autograd.grad(loss, [sd[k] for k in keys], allow_unused=True)
+        times.append(time.time() - t0)
+        if time.time() - t_start > budget_s:
+            break
+    t = min(times)
+    step_s = t * 32.0 / 6.0
+    return {"value": 1.0 / step_s, "unit": "volumes/s", "cores": threads, "kind": "port",
+            "sample": f"1 volume 80x96x80, z=1200 model, encoder+decoder forward+backward (6 of the 32 network "
+                      f"passes of a step) = {t:.2f} s best of {len(times)}, extrapolated x32/6 to a full step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="volumes per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import siv.backend as sb
+    import siv.rng as srng
+    import siv.utils.my_trainer as trainer
+    from siv.optim import FlatAdam
+    from siv.parallel import GradSync, init_process_group
+
+    rank, local_rank, world = init_process_group("nccl")
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    B = sb.get_backend()
+    assert B.name == "hip"
+
+    net = build_model(device)
+    opt_e = FlatAdam(net.encoder.parameters(), lr=2e-4)
+    opt_d = FlatAdam(net.decoder.parameters(), lr=2e-4)
+    sync = GradSync(device)
+    step = trainer.SoftIntroStep(net, opt_e, opt_d, 1.0, 1024.0, 0.75, 1e-8, None, sync)
+    srng.manual_seed(77, rank)
+
+    gen = torch.Generator().manual_seed(103 + rank)        # data seed, z-1200main.py:63
+    n_batches = 2
+    batches = [torch.rand(args.batch, 1, *DIMS, generator=gen).to(device) for _ in range(n_batches)]
+
+    # live timing of the dominant kernel: HIP events on the launch stream around every forward
+    # launch of the 64->64 conv at full resolution inside the timed region
+    dom_events = []
+    recording = {"on": False}
+    orig_fwd = B.conv3d_k3_fwd
+
+    def timed_fwd(x, w, bias, ups=1):
+        hit = (recording["on"] and ups == 1 and w.shape[0] == 64 and w.shape[1] == 64
+               and tuple(x.shape[2:]) == DIMS)
+        if not hit:
+            return orig_fwd(x, w, bias, ups)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = orig_fwd(x, w, bias, ups)
+        e1.record()
+        dom_events.append((e0, e1, x.shape[0]))
+        return y
+
+    B.conv3d_k3_fwd = timed_fwd
+
+    def one_step(i):
+        real = batches[i % n_batches]
+        noise = srng.get_rng().eps(net.latent_shape(real.size(0), DIMS), device)
+        return step(real, noise)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    recording["on"] = True
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = one_step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    recording["on"] = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stats = dict(zip(trainer.STAT_NAMES, last.cpu().tolist()))
+    if not all(v == v for v in stats.values()):
+        raise SystemError(f"NaN in losses: {stats}")
+
+    if rank == 0:
+        ms_per_step = 1000.0 * elapsed / args.steps
+        vols = args.batch * world * args.steps / elapsed
+        dom_ms = [e0.elapsed_time(e1) for e0, e1, _ in dom_events]
+        roof = None
+        if dom_ms:
+            avg_ms = sum(dom_ms) / len(dom_ms)
+            achieved = DOM_FLOP_PER_VOLUME * args.batch / (avg_ms * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "kernel": "k3_fwd_mfma (3x3x3 conv 64->64 @80x96x80, fp32 MFMA 32x32x2)",
+                    "launches_timed": len(dom_ms), "avg_launch_ms": round(avg_ms, 3)}
+        out = {
+            "metric": "MRI volumes/sec (S-IntroVAE step) at 80x96x80 z=1200",
+            "value": round(vols, 4), "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: 80x96x80 fp32, z=1200, "
+                                   "SoftIntroVAE(64,[[64,1,2],[128,1,2],[256,2,2]]), E-step + D-step + 2 Adam updates",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "rng": "device Philox (dropout, eps, noise)"},
+            "roofline": roof,
+            "losses": {k: stats[k] for k in ("lossE", "lossD", "loss_rec", "kl_real")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,307 @@
+"""Model- and step-level parity on a real MI355X: the product path (libsiv through the C ABI)
+against (a) the committed reference-generated fixtures and (b) the CPU oracle run on the spot
+for configurations that exercise the matrix-core and single-channel kernels, plus
+size-independent properties at the full benchmark size (80x96x80, 64-128-256 channels).
+
+Tolerances: 1e-4 relative (of the tensor maximum) for everything continuous -- activations,
+losses, BN statistics.  End-to-end gradients cross ~10^6 LeakyReLU/ReLU kinks; one
+pre-activation landing on the other side of zero in one implementation shifts all upstream
+gradients by 1e-4..1e-3 of their maximum (see tests/test_host_logic.py), so those use 1e-3
+(narrow fixture model) and 2e-3 (wide on-the-spot model); every kernel on the path is pinned
+at 1e-4 by tests/test_gpu_ops.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import siv_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BN_CANCELLED = ("encoder.blocks.0.0.bias", "decoder.blocks.0.0.bias", "decoder.blocks.0.0.weight")
+
+
+@pytest.fixture(autouse=True)
+def hip_backend():
+    import siv.backend as sb
+    import siv.rng as srng
+    sb.set_backend(None)
+    assert sb.get_backend().name == "hip"
+    yield
+    srng.set_rng(srng.DeviceRng(0))
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def sd_from(g, prefix):
+    return {k[len(prefix):]: torch.from_numpy(g[k].copy()) for k in g.files if k.startswith(prefix)}
+
+
+def check(a, b, what, tol=1e-4, floor=0.0):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float32)
+    b = b.detach().float().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float32)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.isfinite(a).all(), what
+    err = float(np.abs(a - b).max())
+    lim = tol * float(np.abs(b).max()) + floor
+    assert err <= lim, f"{what}: max abs err {err:.3e} > {lim:.3e} (max|ref| {np.abs(b).max():.3e})"
+
+
+def test_g3_forward_matches_reference_fixture():
+    import siv.models.models as models
+    import siv.rng as srng
+    g = load("g3_model.npz")
+    net = models.SoftIntroVAE(4, [[4, 1, 2], [8, 1, 2], [8, 2, 2]])
+    net.load_state_dict(sd_from(g, "sd0."))
+    net = net.to("cuda")
+    x, z_in = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["z_in"]).cuda()
+    net.train()
+    with srng.use_rng(srng.ReplayRng(O.Draws(seed=int(g["draw_seed"])))):
+        mu, lv = net.encode(x)
+        xd = net.decode(z_in)
+        fmu, flv, fz, fx = net.forward(x)
+    for a, k in ((mu, "enc.mu"), (lv, "enc.logvar"), (xd, "dec.x"), (fmu, "fwd.mu"),
+                 (flv, "fwd.logvar"), (fz, "fwd.z"), (fx, "fwd.x")):
+        check(a, g[k], k)
+    ref1 = sd_from(g, "sd1.")
+    for k, v in net.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(ref1[k]), k
+        else:
+            check(v, ref1[k], k, floor=1e-6)
+    net.eval()
+    with torch.no_grad():
+        mu, lv = net.encode(x)
+        z = net.reparameterize(mu, lv, True)
+        xe = net.decode(z)
+    for a, k in ((mu, "eval.mu"), (lv, "eval.logvar"), (z, "eval.z"), (xe, "eval.x")):
+        check(a, g[k], k)
+
+
+def _run_steps(net, g_inputs, hp, draws, n_steps, lr=2e-4):
+    import siv.rng as srng
+    import siv.utils.my_trainer as trainer
+    from siv.optim import FlatAdam
+    opt_e = FlatAdam(net.encoder.parameters(), lr=lr)
+    opt_d = FlatAdam(net.decoder.parameters(), lr=lr)
+    step = trainer.SoftIntroStep(net, opt_e, opt_d, hp.beta_rec, hp.beta_neg, hp.beta_kl, hp.gamma_r, hp.scale)
+    grads, out = {}, []
+    oe, od = opt_e.step, opt_d.step
+    opt_e.step = lambda: (grads.update({"encoder." + k: p.grad.detach().clone().cpu()
+                                        for k, p in net.encoder.named_parameters()}), oe())
+    opt_d.step = lambda: (grads.update({"decoder." + k: p.grad.detach().clone().cpu()
+                                        for k, p in net.decoder.named_parameters()}), od())
+    with srng.use_rng(srng.ReplayRng(draws)):
+        for s in range(n_steps):
+            real, noise = g_inputs(s)
+            st = dict(zip(trainer.STAT_NAMES, step(real.cuda(), noise.cuda()).cpu().tolist()))
+            out.append((st, dict(grads)))
+    return out
+
+
+def test_g4_step_matches_reference_fixture():
+    import siv.models.models as models
+    g = load("g4_step.npz")
+    net = models.SoftIntroVAE(4, [[4, 1, 2], [8, 1, 2], [8, 2, 2]])
+    net.load_state_dict(sd_from(g, "sd0."))
+    net = net.to("cuda").train()
+    hp = O.Hyper(beta_rec=float(g["hp.beta_rec"]), beta_neg=float(g["hp.beta_neg"]),
+                 beta_kl=float(g["hp.beta_kl"]), gamma_r=float(g["hp.gamma_r"]), scale=float(g["hp.scale"]))
+    draws = O.Draws(seed=int(g["draw_seed"]))
+    res = _run_steps(net, lambda s: (torch.from_numpy(g[f"s{s}.real"]), torch.from_numpy(g[f"s{s}.noise"])),
+                     hp, draws, 2)
+    assert draws.i == int(g["n_draws"])
+    for s, (st, grads) in enumerate(res):
+        srt = 1e-4 if s == 0 else 1e-3     # iteration 2 starts from weights that differ by Adam sign noise
+        for mine, ref in (("lossE", "lossE"), ("lossD", "lossD"), ("kl_real", "kl_real"),
+                          ("fake_kl", "fake_kl"), ("rec_kl", "rec_kl"), ("loss_rec", "loss_rec_D")):
+            np.testing.assert_allclose(st[mine], float(g[f"s{s}.{ref}"]), rtol=srt, err_msg=f"s{s}.{mine}")
+        for mine in ("exp_elbo_rec", "exp_elbo_fake"):
+            b = float(g[f"s{s}.{mine}"])
+            if b > 1e-44:
+                np.testing.assert_allclose(np.log(max(st[mine], 1e-45)), np.log(b), rtol=srt, err_msg=mine)
+        if s == 0:
+            for k, gr in grads.items():
+                which = "gradE" if k.startswith("encoder.") else "gradD"
+                key = f"s0.{which}.{k}"
+                if key + ".none" in g.files:
+                    assert float(gr.abs().max()) == 0.0, key
+                elif not k.endswith(BN_CANCELLED):
+                    check(gr, g[key], key, tol=1e-3, floor=3e-7)
+    ref_sd = sd_from(g, "s1.sd.")
+    for k, v in net.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(ref_sd[k]), k
+        elif k.endswith(("running_mean", "running_var")):
+            check(v, ref_sd[k], k, tol=2e-3, floor=2e-4)
+
+
+def test_g6_plain_vae_matches_reference_fixture():
+    import siv.models.vaemodel as vaemodel
+    import siv.models.lossf as lossf
+    import siv.rng as srng
+    from siv.optim import FlatAdam
+    g = load("g6_vae.npz")
+    net = vaemodel.ResNetVAE(4, [[4, 1, 2], [6, 1, 2], [8, 2, 2], [12, 2, 2]])
+    net.load_state_dict(sd_from(g, "sd0."))
+    net = net.to("cuda").train()
+    opt = FlatAdam(net.parameters(), 1e-3)
+    with srng.use_rng(srng.ReplayRng(O.Draws(seed=int(g["draw_seed"])))):
+        x = torch.from_numpy(g["s0.x"]).cuda()
+        opt.zero_grad()
+        x_re, mu, logvar = net.forward(x)
+        loss, mse, kl = lossf.normal_loss(x_re, mu, logvar, x, 1, 20)
+        loss.backward()
+        check(torch.stack([loss, mse, kl]), g["s0.loss"], "losses")
+        check(mu, g["s0.mu"], "mu")
+        check(x_re[:, :, 16], g["s0.x_re_slice"], "x_re slice")
+        for k, p in net.named_parameters():
+            key = f"s0.grad.{k}"
+            if key + ".none" in g.files:
+                assert float(p.grad.abs().max()) == 0.0
+            elif not k.endswith(BN_CANCELLED):
+                check(p.grad, g[key], key, tol=1e-3, floor=3e-7)
+        opt.step()
+
+
+WIDE = (64, [[64, 1, 2], [128, 1, 2]])
+
+
+def test_wide_model_step_matches_oracle():
+    """A 64-128 channel model (fp32 matrix-core conv kernels, single-channel stem/tail kernels,
+    x2 upsample fused into the gather) through one full E+D iteration against the CPU oracle
+    computed on the spot (a few seconds of CPU)."""
+    import siv.models.models as models
+    dims, Bn = (16, 16, 16), 2
+    torch.manual_seed(5)
+    net = models.SoftIntroVAE(*WIDE)
+    gen = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for m in net.modules():
+            if type(m) == torch.nn.Conv3d:
+                torch.nn.init.kaiming_normal_(m.weight, nonlinearity="leaky_relu")
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.copy_(1 + 0.2 * torch.randn(m.weight.shape, generator=gen))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    real = torch.rand(Bn, 1, *dims, generator=gen)
+    noise = torch.randn(Bn, 1, 4, 4, 4, generator=gen)
+    cfg, hp = O.Cfg(*WIDE), O.Hyper(dims=dims)
+    ref = O.soft_intro_step(sd, cfg, real, noise, O.Draws(seed=17), hp, {}, {})
+    net = net.to("cuda").train()
+    (st, grads), = _run_steps(net, lambda s: (real, noise), hp, O.Draws(seed=17), 1)
+    for mine, r in (("lossE", "lossE"), ("lossD", "lossD"), ("kl_real", "kl_real"), ("fake_kl", "fake_kl"),
+                    ("rec_kl", "rec_kl"), ("loss_rec", "loss_rec_D")):
+        np.testing.assert_allclose(st[mine], float(ref[r]), rtol=1e-4, err_msg=mine)
+    worst = 0.0
+    for k, gr in grads.items():
+        rg = ref["gradE" if k.startswith("encoder.") else "gradD"][k]
+        if rg is None:
+            assert float(gr.abs().max()) == 0.0, k
+        elif not k.endswith(BN_CANCELLED):
+            check(gr, rg, k, tol=2e-3, floor=3e-7)
+            worst = max(worst, float((gr - rg).abs().max() / (rg.abs().max() + 1e-30)))
+    print(f"wide-model step: worst gradient error {worst:.2e} of max")
+    for k, v in net.state_dict().items():
+        if k.endswith(("running_mean", "running_var")):
+            # the stem's running mean contains its BN-cancelled conv bias, which Adam moves by
+            # +-lr in a noise-determined direction between the E-step and D-step passes
+            check(v, sd[k], k, tol=1e-4, floor=5e-4 if k.endswith("blocks.0.1.running_mean") else 1e-5)
+
+
+def test_eval_forward_wide_matches_oracle():
+    import siv.models.models as models
+    torch.manual_seed(8)
+    net = models.SoftIntroVAE(*WIDE)
+    gen = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.running_mean.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+                m.running_var.copy_(0.5 + torch.rand(m.bias.shape, generator=gen))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.rand(1, 1, 8, 16, 24, generator=gen)
+    cfg = O.Cfg(*WIDE)
+    mu_r, lv_r = O.encode(x, sd, cfg, None, False)
+    z_r = O.reparameterize(mu_r, lv_r, None, True)
+    x_r = O.decode(z_r, sd, cfg, None, False)
+    net = net.to("cuda").eval()
+    with torch.no_grad():
+        mu, lv = net.encode(x.cuda())
+        z = net.reparameterize(mu, lv, True)
+        xe = net.decode(z)
+    check(mu, mu_r, "mu")
+    check(lv, lv_r, "logvar")
+    check(z, z_r, "z")
+    check(xe, x_r, "x_re")
+
+
+# ---------------------------------------------------------------------------------------
+# full benchmark size: size-independent properties (no oracle needed)
+# ---------------------------------------------------------------------------------------
+FULL = (80, 96, 80)
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+@pytest.mark.parametrize("cin,cout,dims,n,ups", [
+    (64, 64, FULL, 1, 1),            # 60 % of the model's FLOPs
+    (64, 64, FULL, 1, 2),            # decoder's last block: x2 upsample fused
+    (1, 64, FULL, 2, 1),             # encoder stem
+    (64, 1, FULL, 2, 1),             # decoder output layer
+    (128, 128, (20, 24, 20), 2, 1), (256, 256, (10, 12, 10), 8, 1), (256, 128, (20, 24, 20), 1, 2),
+])
+def test_full_size_conv_adjoint_identities(cin, cout, dims, n, ups):
+    """<conv(x,w), dy> == <x, dgrad(dy,w)> == <w, wgrad(x,dy)>: the three kernels of a layer must be
+    exact adjoints of one another (bilinearity), at the sizes the benchmark runs."""
+    import siv.backend as sb
+    B = sb.get_backend()
+    gen = torch.Generator(device="cuda").manual_seed(cin + cout + ups)
+    D, H, W = dims
+    x = torch.randn(n, cin, D // ups, H // ups, W // ups, device="cuda", generator=gen).contiguous(
+        memory_format=torch.channels_last_3d)
+    w = (torch.randn(cout, cin, 3, 3, 3, device="cuda", generator=gen) * (2.0 / (27 * cin)) ** 0.5).contiguous(
+        memory_format=torch.channels_last_3d)
+    dy = torch.randn(n, cout, D, H, W, device="cuda", generator=gen).contiguous(memory_format=torch.channels_last_3d)
+    y = B.conv3d_k3_fwd(x, w, None, ups)
+    dx = B.conv3d_k3_dgrad(dy, w, ups)
+    dw, _ = B.conv3d_k3_wgrad(x, dy, ups, False)
+    a, b, c = _dot(y, dy), _dot(x, dx), _dot(w, dw)
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(a - b) <= 1e-5 * scale and abs(a - c) <= 1e-5 * scale, (a, b, c, scale)
+    # linearity: conv(2x) == 2 conv(x) exactly in fp32 (power-of-two scaling)
+    y2 = B.conv3d_k3_fwd(x * 2, w, None, ups)
+    assert torch.equal(y2, y * 2)
+    # a delta input reads the kernel back: y[:, :, 1+kd', 1+kh', 1+kw'] = w[:, ci, 2-kd', ...]
+    if ups == 1:
+        xd = torch.zeros_like(x[:1])
+        xd[0, 0, 2, 2, 2] = 1.0
+        yd = B.conv3d_k3_fwd(xd, w, None, 1)
+        assert torch.equal(yd[0, :, 1:4, 1:4, 1:4].cpu(), w[:, 0].flip(1, 2, 3).cpu())
+
+
+def test_full_size_bn_tail_properties():
+    import siv.backend as sb
+    B = sb.get_backend()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    y = (torch.randn(2, 64, *FULL, device="cuda", generator=gen) * 3 + 1).contiguous(
+        memory_format=torch.channels_last_3d)
+    ones, zeros = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda")
+    mean, var = B.bn_stats(y, None, None, None, 0.1)
+    out = B.bn_act_fwd(y, mean, var, ones, zeros, None, None, 0.0, 1.0, 1, 1e-5)    # slope 1 = identity act
+    m2, v2 = B.bn_stats(out, None, None, None, 0.1)
+    assert float(m2.abs().max()) < 1e-4 and float((v2 - 1).abs().max()) < 1e-4       # normalised
+    pooled = B.bn_act_fwd(y, mean, var, ones, zeros, None, None, 0.0, 1.0, 2, 1e-5)
+    assert pooled.shape == (2, 64, 40, 48, 40)
+    ref = torch.nn.functional.avg_pool3d(out, 2)
+    assert float((pooled - ref).abs().max()) < 1e-5
+    # gradient of sum(out) w.r.t. y is zero through training-mode BN (mean subtraction)
+    dout = torch.ones_like(out)
+    dy, dg, db, _ = B.bn_act_bwd(dout, y, mean, var, ones, zeros, None, None, 0.0, 1.0, 1, 1e-5, True, False)
+    assert float(dy.abs().max()) < 1e-5
+    assert abs(float(db[0]) - 2 * 80 * 96 * 80) < 1.0

@@ -1,0 +1,325 @@
+"""Per-operator parity: every libsiv entry point, called through the C ABI (ctypes) on a real
+MI355X, against the CPU oracle on the same seeded inputs.
+
+Tolerance (the bar BASELINE.json's north_star states): 1e-4 relative fp32, measured as
+max|hip - oracle| <= 1e-4 * max|oracle| per output tensor.  The backward of the BN/activation
+tail contains LeakyReLU/ReLU kinks: an element whose pre-activation is within rounding of zero
+may legitimately take the other branch, so those comparisons allow a handful of outlier
+elements (reported) instead of loosening the tolerance."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import siv_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def B():
+    import siv.backend as sb
+    sb.set_backend(None)
+    b = sb.get_backend()
+    assert b.name == "hip"
+    yield b
+    b.set_conv_path(0)
+
+
+def dev(t):
+    return None if t is None else t.to("cuda")
+
+
+def relerr(a, b):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def check(a, b, what, tol=TOL, max_outliers=0):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.isfinite(a).all(), what
+    scale = float(b.abs().max()) + 1e-30
+    bad = ((a - b).abs() > tol * scale)
+    nbad = int(bad.sum())
+    assert nbad <= max_outliers, f"{what}: {nbad} elements beyond {tol} of max (rel err {relerr(a, b):.3e})"
+
+
+def rnd(gen, *shape, scale=1.0):
+    return torch.randn(*shape, generator=gen) * scale
+
+
+# (Cin, Cout, dims, N, ups, path) -- path 0 = automatic dispatch, 1 = generic kernels
+CONV_CASES = [
+    (1, 4, (6, 7, 5), 1, 1, 0), (4, 4, (6, 7, 5), 3, 1, 0), (4, 8, (8, 12, 8), 1, 1, 0),
+    (8, 4, (8, 12, 8), 3, 1, 0), (4, 1, (6, 7, 5), 3, 1, 0), (3, 5, (5, 4, 3), 2, 1, 0),
+    (4, 8, (8, 12, 8), 2, 2, 0), (6, 6, (4, 6, 4), 2, 2, 0),
+    # single-channel-side kernels (encoder stem / decoder output layer)
+    (1, 8, (8, 12, 8), 2, 1, 0), (1, 64, (9, 10, 11), 2, 1, 0), (1, 12, (6, 7, 5), 1, 1, 0),
+    (8, 1, (8, 12, 8), 2, 1, 0), (64, 1, (9, 10, 11), 2, 1, 0), (16, 1, (6, 7, 5), 3, 1, 0),
+    # fp32 matrix-core kernels
+    (8, 64, (8, 12, 8), 1, 1, 0), (64, 64, (8, 12, 8), 2, 1, 0), (64, 64, (5, 7, 9), 1, 1, 0),
+    (16, 128, (10, 12, 10), 2, 1, 0), (128, 64, (4, 8, 8), 1, 1, 0), (64, 128, (3, 5, 17), 1, 1, 0),
+    (64, 64, (8, 12, 8), 2, 2, 0), (128, 64, (8, 8, 16), 1, 2, 0), (256, 256, (2, 4, 8), 1, 1, 0),
+    (64, 64, (16, 16, 16), 1, 1, 0),
+    # the same wide shapes through the generic kernels (cross-check of the dispatcher)
+    (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
+]
+
+
+@pytest.mark.parametrize("cin,cout,dims,n,ups,path", CONV_CASES)
+def test_conv3d_k3_fwd_dgrad_wgrad(B, cin, cout, dims, n, ups, path):
+    gen = torch.Generator().manual_seed(cin * 1000 + cout * 10 + dims[0] + ups)
+    D, H, W = dims
+    x = rnd(gen, n, cin, D // ups, H // ups, W // ups)
+    w = rnd(gen, cout, cin, 3, 3, 3, scale=(2.0 / (27 * cin)) ** 0.5)
+    b = rnd(gen, cout)
+    dy = rnd(gen, n, cout, D, H, W)
+    B.set_conv_path(path)
+    try:
+        y = B.conv3d_k3_fwd(dev(x), dev(w), dev(b), ups)
+        y_nb = B.conv3d_k3_fwd(dev(x), dev(w), None, ups)
+        dx = B.conv3d_k3_dgrad(dev(dy), dev(w), ups)
+        dw, db = B.conv3d_k3_wgrad(dev(x), dev(dy), ups, True)
+        dw2, db2 = B.conv3d_k3_wgrad(dev(x), dev(dy), ups, False)
+    finally:
+        B.set_conv_path(0)
+    assert db2 is None
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    yr = O.conv3d_k3(xr, wr, br, ups)
+    gx, gw, gb = torch.autograd.grad(yr, [xr, wr, br], dy)
+    check(y, yr, "fwd")
+    check(y_nb, O.conv3d_k3(x, w, None, ups), "fwd (no bias)")
+    check(dx, gx, "dgrad")
+    check(dw, gw, "wgrad")
+    check(dw2, gw, "wgrad (no bias)")
+    check(db, gb, "bias grad")
+    assert y.is_contiguous(memory_format=torch.channels_last_3d)
+
+
+def test_conv_rejects_bad_arguments(B):
+    import siv._lib as L
+    x = torch.zeros(1, 4, 3, 3, 3, device="cuda")
+    w = torch.zeros(4, 4, 3, 3, 3, device="cuda")
+    with pytest.raises(L.SivError):
+        B.conv3d_k3_fwd(x, w, None, 3)                      # ups must be 1 or 2
+    with pytest.raises(L.SivError):
+        B.conv3d_k3_fwd(x.cpu(), w.cpu(), None, 1)          # no CPU fallback
+    lib = L.load()
+    assert lib.siv_conv3d_k3_fwd(None, None, None, None, 1, 1, 1, 1, 1, 1, 1, None, 0, None) != 0
+    assert b"null" in lib.siv_last_error()
+    B.set_conv_path(2)
+    try:
+        with pytest.raises(L.SivError):
+            B.conv3d_k3_fwd(torch.zeros(1, 3, 4, 4, 4, device="cuda"),
+                            torch.zeros(5, 3, 3, 3, 3, device="cuda"), None, 1)
+    finally:
+        B.set_conv_path(0)
+
+
+@pytest.mark.parametrize("cin,cout", [(8, 1), (1, 8), (256, 1), (6, 10), (64, 2)])
+def test_conv1x1(B, cin, cout):
+    gen = torch.Generator().manual_seed(cin + cout)
+    x = rnd(gen, 3, cin, 4, 6, 5)
+    w = rnd(gen, cout, cin, 1, 1, 1)
+    b = rnd(gen, cout)
+    dy = rnd(gen, 3, cout, 4, 6, 5)
+    y = B.conv1x1_fwd(dev(x), dev(w), dev(b))
+    dx = B.conv1x1_dgrad(dev(dy), dev(w))
+    dw, db = B.conv1x1_wgrad(dev(x), dev(dy), True)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv3d(xr, wr, br)
+    gx, gw, gb = torch.autograd.grad(yr, [xr, wr, br], dy)
+    check(y, yr, "fwd")
+    check(dx, gx, "dgrad")
+    check(dw, gw, "wgrad")
+    check(db, gb, "bias grad")
+
+
+def test_upsample2_bwd(B):
+    import siv._lib as L
+    gen = torch.Generator().manual_seed(3)
+    dy = rnd(gen, 2, 6, 4, 6, 8)
+    dx = torch.empty(2, 6, 2, 3, 4, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+    g = dev(dy).contiguous(memory_format=torch.channels_last_3d)
+    L.check(B.lib.siv_upsample2_bwd(g.data_ptr(), dx.data_ptr(), 2, 4, 6, 8, 6, 0), "upsample2_bwd")
+    torch.cuda.synchronize()
+    check(dx, F.avg_pool3d(dy, 2) * 8, "upsample2_bwd")
+
+
+@pytest.mark.parametrize("c,dims,n", [(4, (6, 7, 5), 3), (64, (8, 12, 8), 2), (12, (4, 4, 4), 1),
+                                      (256, (2, 3, 2), 3), (1, (5, 5, 5), 2), (300, (2, 2, 2), 2)])
+def test_bn_stats(B, c, dims, n):
+    gen = torch.Generator().manual_seed(c)
+    y = rnd(gen, n, c, *dims) * (1 + torch.arange(c).view(1, c, 1, 1, 1) % 5) + \
+        10.0 * torch.randn(c, generator=gen).view(1, c, 1, 1, 1)       # mean >> std in places
+    rm, rv = rnd(gen, c), torch.rand(c, generator=gen) + 0.5
+    nbt = torch.tensor(7, dtype=torch.int64)
+    rm_d, rv_d, nbt_d = dev(rm.clone()), dev(rv.clone()), dev(nbt.clone())
+    mean, var = B.bn_stats(dev(y), rm_d, rv_d, nbt_d, 0.1)
+    F.batch_norm(y, rm, rv, None, None, True, 0.1, 1e-5)
+    check(mean, y.mean(dim=(0, 2, 3, 4)), "mean")
+    check(var, y.var(dim=(0, 2, 3, 4), unbiased=False), "var")
+    check(rm_d, rm, "running_mean")
+    check(rv_d, rv, "running_var")
+    assert int(nbt_d) == 8
+    mean2, var2 = B.bn_stats(dev(y), None, None, None, 0.1)      # statistics only
+    check(mean2, mean, "mean (no running)", tol=0)
+
+
+BN_CASES = [  # c, dims, n, slope, pool, residual, dropout p
+    (4, (6, 8, 4), 3, 0.2, 1, False, 0.0), (4, (6, 8, 4), 3, 0.2, 2, False, 0.0),
+    (8, (4, 6, 4), 2, 0.2, 1, True, 0.0), (8, (4, 6, 4), 2, 0.0, 1, True, 0.0),
+    (64, (8, 12, 8), 2, 0.2, 1, False, 0.35), (64, (8, 12, 8), 1, 0.2, 2, False, 0.0),
+    (12, (4, 4, 4), 2, 0.0, 2, False, 0.0), (256, (2, 3, 2), 3, 0.2, 1, True, 0.25),
+]
+
+
+@pytest.mark.parametrize("c,dims,n,slope,pool,use_res,p", BN_CASES)
+def test_bn_act_fwd_bwd(B, c, dims, n, slope, pool, use_res, p):
+    gen = torch.Generator().manual_seed(c + pool + int(slope * 10))
+    y = rnd(gen, n, c, *dims) * 2 + 0.5
+    gamma, beta = 1 + 0.3 * rnd(gen, c), 0.2 * rnd(gen, c)
+    res = rnd(gen, n, c, *dims) if use_res else None
+    odims = tuple(d // pool for d in dims)
+    keep = (torch.rand(n, c, *odims, generator=gen) >= p).float() if p > 0 else None
+    dout = rnd(gen, n, c, *odims)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    yr, gr, br = y.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if use_res else None
+    ref = O.bn_act(yr, gr, br, rm.clone(), rv.clone(), slope, pool, rr, keep, p, True)
+    grads = torch.autograd.grad(ref, [yr, gr, br] + ([rr] if use_res else []), dout)
+
+    mean, var = B.bn_stats(dev(y), None, None, None, 0.1)
+    keep_d = dev(keep.to(torch.uint8)) if keep is not None else None
+    out = B.bn_act_fwd(dev(y), mean, var, dev(gamma), dev(beta), dev(res), keep_d, p, slope, pool, 1e-5)
+    check(out, ref, "fwd")
+    dy, dg, db, dres = B.bn_act_bwd(dev(dout), dev(y), mean, var, dev(gamma), dev(beta), dev(res), keep_d,
+                                    p, slope, pool, 1e-5, True, use_res)
+    check(dy, grads[0], "dy", max_outliers=3)
+    check(dg, grads[1], "dgamma", tol=2e-4)
+    check(db, grads[2], "dbeta", tol=2e-4)
+    if use_res:
+        check(dres, grads[3], "dres", max_outliers=3)
+    dy2, dg2, db2, dres2 = B.bn_act_bwd(dev(dout), dev(y), mean, var, dev(gamma), dev(beta), dev(res), keep_d,
+                                        p, slope, pool, 1e-5, False, False)
+    assert dg2 is None and db2 is None and dres2 is None
+    check(dy2, dy, "dy (no affine grads)", tol=0)
+    # evaluation mode: running statistics in place of batch statistics
+    rm2, rv2 = rnd(gen, c), torch.rand(c, generator=gen) + 0.5
+    out_e = B.bn_act_fwd(dev(y), dev(rm2), dev(rv2), dev(gamma), dev(beta), dev(res), None, 0.0, slope, pool, 1e-5)
+    check(out_e, O.bn_act(y, gamma, beta, rm2, rv2, slope, pool, res, None, 0.0, False), "eval fwd")
+
+
+def test_act_dropout(B):
+    gen = torch.Generator().manual_seed(11)
+    x = rnd(gen, 2, 1, 6, 7, 5)
+    keep = (torch.rand(2, 1, 6, 7, 5, generator=gen) >= 0.35).float()
+    dout = rnd(gen, 2, 1, 6, 7, 5)
+    for slope in (0.0, 0.2):
+        xr = x.clone().requires_grad_(True)
+        ref = O.act(xr, slope) * keep * (1 / (1 - 0.35))
+        gx, = torch.autograd.grad(ref, xr, dout)
+        out = B.act_dropout_fwd(dev(x), dev(keep.to(torch.uint8)), 0.35, slope)
+        dx = B.act_dropout_bwd(dev(dout), dev(x), dev(keep.to(torch.uint8)), 0.35, slope)
+        check(out, ref, "fwd")
+        check(dx, gx, "bwd")
+        check(B.act_dropout_fwd(dev(x), None, 0.0, slope), O.act(x, slope), "fwd (no dropout)")
+
+
+def test_reparam_kl_sse(B):
+    gen = torch.Generator().manual_seed(12)
+    mu, lv = rnd(gen, 4, 1, 2, 3, 2) * 3, rnd(gen, 4, 1, 2, 3, 2) * 2
+    lv[0, 0, 0, 0, 0], lv[1, 0, 0, 0, 0] = 30.0, -30.0                 # extreme log-variances
+    eps = rnd(gen, 4, 1, 2, 3, 2)
+    dz = rnd(gen, 4, 1, 2, 3, 2)
+    mr, lr_ = mu.clone().requires_grad_(True), lv.clone().requires_grad_(True)
+    zr = mr + eps * torch.exp(0.5 * lr_)
+    gm, gl = torch.autograd.grad(zr, [mr, lr_], dz)
+    z = B.reparam_fwd(dev(mu), dev(lv), dev(eps), 0.0)
+    dmu, dlv = B.reparam_bwd(dev(dz), dev(lv), dev(eps), 0.0)
+    check(z, zr, "z")
+    check(dmu, gm, "dmu")
+    check(dlv, gl, "dlogvar")
+    check(B.reparam_fwd(dev(mu), dev(lv), None, 0.1), mu + 0.1 * torch.exp(0.5 * lv), "z (eps=0.1)")
+    # KL
+    g = rnd(gen, 4)
+    mr, lr_ = mu.clone().requires_grad_(True), lv.clone().requires_grad_(True)
+    klr = O.calc_kl(lr_, mr, "none")
+    gm, gl = torch.autograd.grad(klr, [mr, lr_], g)
+    kl = B.kl_fwd(dev(mu), dev(lv))
+    dmu, dlv = B.kl_bwd(dev(g), dev(mu), dev(lv))
+    check(kl, klr, "kl")
+    check(dmu, gm, "kl dmu")
+    check(dlv, gl, "kl dlogvar")
+    # SSE, including a size that is not a multiple of anything
+    for shape in ((4, 1, 6, 5, 7), (3, 1, 16, 24, 16)):
+        x, y = torch.rand(*shape, generator=gen), torch.rand(*shape, generator=gen)
+        g = rnd(gen, shape[0])
+        xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+        ser = O.calc_reconstruction_loss(xr, yr, "none")
+        gx, gy = torch.autograd.grad(ser, [xr, yr], g)
+        se = B.sse_fwd(dev(x), dev(y))
+        dx, dy = B.sse_bwd(dev(g), dev(x), dev(y), True, True)
+        check(se, ser, "sse")
+        check(dx, gx, "sse dx")
+        check(dy, gy, "sse dy")
+        dx2, dy2 = B.sse_bwd(dev(g), dev(x), dev(y), False, True)
+        assert dx2 is None
+        check(dy2, gy, "sse dy only")
+    assert float(B.sse_fwd(dev(x), dev(x)).abs().max()) == 0.0
+    zero = torch.zeros(2, 1, 2, 3, 2, device="cuda")
+    assert float(B.kl_fwd(zero, zero).abs().max()) == 0.0
+
+
+def test_adam_matches_torch(B):
+    gen = torch.Generator().manual_seed(13)
+    n = 1000 + 37
+    p0 = rnd(gen, n)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=2e-4)
+    p, m, v = dev(p0.clone()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 6):
+        g = rnd(gen, n) * (10.0 ** (step - 3))
+        g[::7] = 0.0
+        ref.grad = g.clone()
+        opt.step()
+        B.adam_step(p, dev(g), m, v, 2e-4, 0.9, 0.999, 1e-8, step)
+        assert float((p.cpu() - ref.detach()).abs().max()) <= 1e-6, step
+    zeros = torch.zeros(n, device="cuda")                    # zero gradient => parameter untouched
+    p2, m2, v2 = dev(p0.clone()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    B.adam_step(p2, zeros, m2, v2, 2e-4, 0.9, 0.999, 1e-8, 1)
+    assert torch.equal(p2.cpu(), p0)
+
+
+def test_device_rng_statistics(B):
+    n = 1 << 20
+    a = B.randn((n,), torch.device("cuda"), 77, 5).cpu()
+    b = B.randn((n,), torch.device("cuda"), 77, 5).cpu()
+    c = B.randn((n,), torch.device("cuda"), 77, 6).cpu()
+    assert torch.equal(a, b) and not torch.equal(a, c)           # counter based: reproducible, stream-keyed
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
+    assert abs(float((a ** 4).mean()) - 3.0) < 0.1               # normal kurtosis
+    assert torch.isfinite(a).all()
+    odd = B.randn((3, 1, 5, 7, 3), torch.device("cuda"), 1, 0)
+    assert odd.shape == (3, 1, 5, 7, 3) and torch.isfinite(odd).all()
+    for p in (0.25, 0.35):
+        k = B.dropout_keep((2, 8, 16, 16, 16), torch.device("cuda"), p, 77, 9).cpu()
+        assert k.dtype == torch.uint8 and set(k.unique().tolist()) <= {0, 1}
+        assert abs(float(k.float().mean()) - (1 - p)) < 3e-3
+
+
+def test_axpby(B):
+    gen = torch.Generator().manual_seed(14)
+    x, y = rnd(gen, 1001), rnd(gen, 1001)
+    yd = dev(y.clone())
+    B.axpby(0.5, dev(x), 2.0, yd)
+    check(yd, 0.5 * x + 2.0 * y, "axpby")
+    B.axpby(0.25, yd, 0.0, yd)                                   # in-place scaling
+    check(yd, 0.25 * (0.5 * x + 2.0 * y), "scale")
