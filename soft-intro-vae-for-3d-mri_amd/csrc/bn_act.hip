@@ -68,6 +68,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     }
 }
 
+// one wave per channel: lanes stride over the per-block partials, fixed-order wave reduction
 __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ y,
                                                          const float* __restrict__ part, int nblk,
                                                          long M, int C, float* __restrict__ mean,
@@ -75,14 +76,18 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
                                                          float* __restrict__ rmean,
                                                          float* __restrict__ rvar,
                                                          int64_t* __restrict__ nbt, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
         s1 += (double)part[((long)b * 2 + 0) * C + c];
         s2 += (double)part[((long)b * 2 + 1) * C + c];
     }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane != 0) return;
     const double ms = s1 / (double)M;
     double v = s2 / (double)M - ms * ms;
     if (v < 0.0) v = 0.0;
@@ -222,18 +227,22 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
     }
 }
 
-// sums[0][c] = sum dz, sums[1][c] = sum dz*xhat; also dgamma/dbeta
+// sums[0][c] = sum dz, sums[1][c] = sum dz*xhat; also dgamma/dbeta.  One wave per channel.
 __global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__ part, int nblk, int C,
                                                        float* __restrict__ sums,
                                                        float* __restrict__ dgamma,
                                                        float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
         s1 += (double)part[((long)b * 2 + 0) * C + c];
         s2 += (double)part[((long)b * 2 + 1) * C + c];
     }
+    s1 = wave_sum_d(s1);
+    s2 = wave_sum_d(s2);
+    if (lane != 0) return;
     sums[c] = (float)s1;
     sums[C + c] = (float)s2;
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
@@ -323,7 +332,7 @@ extern "C" int siv_bn_stats(const float* y, long M, int C, float* mean, float* v
     hipStream_t s = (hipStream_t)stream;
     bn_stats_partial<<<nblk, 256, 512 * sizeof(float), s>>>(y, M, C, (float*)ws);
     SIV_CHECK_LAUNCH("bn_stats(partial)");
-    bn_stats_finalize<<<(C + 255) / 256, 256, 0, s>>>(y, (const float*)ws, nblk, M, C, mean, var,
+    bn_stats_finalize<<<(C + 3) / 4, 256, 0, s>>>(y, (const float*)ws, nblk, M, C, mean, var,
                                                       running_mean, running_var,
                                                       num_batches_tracked, momentum);
     SIV_CHECK_LAUNCH("bn_stats(finalize)");
@@ -381,7 +390,7 @@ extern "C" int siv_bn_act_bwd(const float* dout, const float* y, const float* me
                                                                  residual, keep, p, slope, eps, M, D,
                                                                  H, W, C, part);
     SIV_CHECK_LAUNCH("bn_act_bwd(partial)");
-    bn_bwd_finalize<<<(C + 255) / 256, 256, 0, s>>>(part, nblk, C, sums, dgamma, dbeta, accumulate);
+    bn_bwd_finalize<<<(C + 3) / 4, 256, 0, s>>>(part, nblk, C, sums, dgamma, dbeta, accumulate);
     SIV_CHECK_LAUNCH("bn_act_bwd(finalize)");
     if (pool == 1)
         bn_bwd_apply<1><<<stream_grid(M * C), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual,

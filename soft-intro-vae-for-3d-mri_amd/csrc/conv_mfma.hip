@@ -13,6 +13,12 @@
 // B[k = l>>5][j = l&31]; accumulator register r of lane l is D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
 #include "siv_common.h"
 
+// SIV_EXP is a timing-only ablation mask used by tools/ubench (never set in the library build):
+// 1 = no weight-fragment loads, 2 = no LDS fragment reads, 4 = no halo staging.
+#ifndef SIV_EXP
+#define SIV_EXP 0
+#endif
+
 namespace siv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -20,8 +26,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------------
 // forward (and dgrad through transformed weights)
 // ---------------------------------------------------------------------------------
-template <int BD, int BH, int BW, int WM, int WN, int CK, int UPS>
+// Weights are first re-packed (a 7 MB copy at most) into the order the kernel consumes them:
+//   wp[co_tile][ci_chunk][tap][co (64)][ci (8)]
+// so that the B fragments of one (chunk, tap) are 2 KB of contiguous memory that every wave
+// reads with one coalesced 16-byte load per lane, straight into registers and one tap ahead
+// of its use.  Only the input halo goes through LDS: one barrier pair per 8-channel chunk
+// (27 taps = 432 MFMAs per wave) instead of one per weight slice.
+template <int BD, int BH, int BW, int WM, int WN, int UPS>
 struct FwdCfg {
+    static constexpr int CK = 8;               // input channels per chunk
     static constexpr int M = BD * BH * BW;
     static constexpr int MS = M / 32;          // 32-row sub-tiles in the brick
     static constexpr int NS = 2;               // 64 output channels per block
@@ -31,22 +44,18 @@ struct FwdCfg {
     static constexpr int HV = HD * HH * HW;
     static constexpr int CKP = CK + 4;         // padded channel stride (keeps 16-B alignment)
     static constexpr int HAL_FLOATS = HV * CKP;
-    static constexpr int WL_FLOATS = 9 * 64 * CKP;
-    static constexpr size_t LDS_BYTES = (size_t)(HAL_FLOATS + WL_FLOATS) * sizeof(float);
+    static constexpr size_t LDS_BYTES = (size_t)HAL_FLOATS * sizeof(float);
     static_assert(M % 32 == 0 && MS % WM == 0 && NS % WN == 0 && WM * WN == 4, "bad tiling");
-    static_assert(CK % 8 == 0, "CK must be a multiple of 8");
 };
 
-template <int BD, int BH, int BW, int WM, int WN, int CK, int UPS>
+template <int BD, int BH, int BW, int WM, int WN, int UPS>
 __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
-                                                   const float* __restrict__ w,
+                                                   const float* __restrict__ wp,
                                                    const float* __restrict__ bias,
                                                    float* __restrict__ y, int N, int D, int H, int W,
                                                    int Cin, int Cout, int nbd, int nbh, int nbw) {
-    using C = FwdCfg<BD, BH, BW, WM, WN, CK, UPS>;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* hal = lds;
-    float* wl = lds + C::HAL_FLOATS;
+    using C = FwdCfg<BD, BH, BW, WM, WN, UPS>;
+    extern __shared__ __attribute__((aligned(16))) float hal[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -61,6 +70,7 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
     const int z0 = bz * BD, y0 = by * BH, x0 = bx * BW;
     const int co0 = blockIdx.y * 64;
     const int Di = D / UPS, Hi = H / UPS, Wi = W / UPS;
+    const int nchunk = Cin / C::CK;
 
     f32x16 acc[C::AM][C::AN];
 #pragma unroll
@@ -78,58 +88,90 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
         const int dz = m / (BH * BW), dy = (m / BW) % BH, dx = m % BW;
         aoff[a] = ((dz * C::HH + dy) * C::HW + dx) * C::CKP + 4 * lh;
     }
-    int boff[C::AN];
-#pragma unroll
-    for (int bb = 0; bb < C::AN; ++bb) boff[bb] = ((wn * C::AN + bb) * 32 + li) * C::CKP + 4 * lh;
+    // this lane's B fragment inside a packed [64][8] tap slice: co = (wn*AN + bb)*32 + li, ci 4*lh..
+    const float* wlane = wp + (long)blockIdx.y * nchunk * 27 * 512 + (wn * C::AN * 32 + li) * 8 + 4 * lh;
 
-    constexpr int Q = CK / 4;  // float4 per voxel per chunk
-    for (int c0 = 0; c0 < Cin; c0 += CK) {
-        __syncthreads();  // previous chunk's MFMAs are done with hal/wl
-        for (int idx = tid; idx < C::HV * Q; idx += 256) {
-            const int hv = idx / Q, q = idx % Q;
+    float4 bnext[C::AN];
+#pragma unroll
+    for (int bb = 0; bb < C::AN; ++bb) bnext[bb] = *reinterpret_cast<const float4*>(wlane + bb * 256);
+
+    // The halo of chunk cc+1 is fetched into registers while chunk cc is being multiplied, and
+    // only written to LDS between the two barriers: global-memory latency stays off the
+    // critical path of the block.
+    constexpr int NH = (C::HV * 2 + 255) / 256;
+    float4 hreg[NH];
+    auto load_halo = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int idx = tid + 256 * i;
+            const int hv = idx >> 1, q = idx & 1;
             const int hx = hv % C::HW, hy = (hv / C::HW) % C::HH, hz = hv / (C::HW * C::HH);
             const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            if (!(SIV_EXP & 4) && hv < C::HV && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
                 const long off =
                     ((((long)n * Di + gz / UPS) * Hi + gy / UPS) * Wi + gx / UPS) * Cin + c0 + 4 * q;
                 v = *reinterpret_cast<const float4*>(x + off);
             }
-            *reinterpret_cast<float4*>(hal + hv * C::CKP + 4 * q) = v;
+            hreg[i] = v;
         }
-        for (int kd = 0; kd < 3; ++kd) {
-            if (kd) __syncthreads();  // previous kd's MFMAs are done with wl
-            for (int idx = tid; idx < 9 * 64 * Q; idx += 256) {
-                const int q = idx % Q, co = (idx / Q) % 64, t = idx / (Q * 64);
-                const long off = ((long)(co0 + co) * 27 + kd * 9 + t) * Cin + c0 + 4 * q;
-                *reinterpret_cast<float4*>(wl + (t * 64 + co) * C::CKP + 4 * q) =
-                    *reinterpret_cast<const float4*>(w + off);
-            }
-            __syncthreads();
+    };
+    load_halo(0);
+    for (int cc = 0; cc < nchunk; ++cc) {
+        __syncthreads();  // previous chunk's MFMAs are done with the halo
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int kh = t / 3, kw = t % 3;
-                const int tapoff = ((kd * C::HH + kh) * C::HW + kw) * C::CKP;
+        for (int i = 0; i < NH; ++i) {
+            const int idx = tid + 256 * i;
+            if ((idx >> 1) < C::HV)
+                *reinterpret_cast<float4*>(hal + (idx >> 1) * C::CKP + 4 * (idx & 1)) = hreg[i];
+        }
+        __syncthreads();
+        if (cc + 1 < nchunk) load_halo((cc + 1) * C::CK);
+        const float* wc = wlane + (long)cc * 27 * 512;
+        // A fragments are read one tap ahead of their MFMAs as well, so that neither the LDS
+        // nor the weight loads are waited for right after they are issued
+        float4 anext[C::AM];
 #pragma unroll
-                for (int g = 0; g < CK / 8; ++g) {
-                    float4 av[C::AM], bv[C::AN];
+        for (int a = 0; a < C::AM; ++a) {
+            if (SIV_EXP & 2) anext[a] = make_float4(0.f, 1.f, 2.f, 3.f);
+            else anext[a] = *reinterpret_cast<const float4*>(hal + aoff[a]);
+        }
 #pragma unroll
-                    for (int a = 0; a < C::AM; ++a)
-                        av[a] = *reinterpret_cast<const float4*>(hal + aoff[a] + tapoff + 8 * g);
+        for (int t = 0; t < 27; ++t) {
+            float4 bv[C::AN], av[C::AM];
 #pragma unroll
-                    for (int bb = 0; bb < C::AN; ++bb)
-                        bv[bb] = *reinterpret_cast<const float4*>(wl + boff[bb] + t * 64 * C::CKP + 8 * g);
+            for (int bb = 0; bb < C::AN; ++bb) bv[bb] = bnext[bb];
 #pragma unroll
-                    for (int a = 0; a < C::AM; ++a)
+            for (int a = 0; a < C::AM; ++a) av[a] = anext[a];
+            // prefetch the next tap's fragments (the first tap of the next chunk after the last one;
+            // the packed buffer carries one slice of padding so that this never leaves it)
 #pragma unroll
-                        for (int bb = 0; bb < C::AN; ++bb) {
-                            acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].x, bv[bb].x, acc[a][bb], 0, 0, 0);
-                            acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].y, bv[bb].y, acc[a][bb], 0, 0, 0);
-                            acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].z, bv[bb].z, acc[a][bb], 0, 0, 0);
-                            acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].w, bv[bb].w, acc[a][bb], 0, 0, 0);
-                        }
+            for (int bb = 0; bb < C::AN; ++bb)
+                if (!(SIV_EXP & 1)) bnext[bb] = *reinterpret_cast<const float4*>(wc + (t + 1) * 512 + bb * 256);
+            if (t + 1 < 27) {
+                const int t1 = t + 1;
+                const int tapoff = (((t1 / 9) * C::HH + (t1 / 3) % 3) * C::HW + t1 % 3) * C::CKP;
+#pragma unroll
+                for (int a = 0; a < C::AM; ++a) {
+                    if (SIV_EXP & 2) {
+                        asm volatile("" : "+v"(anext[a].x), "+v"(anext[a].y), "+v"(anext[a].z), "+v"(anext[a].w));
+                    } else {
+                        anext[a] = *reinterpret_cast<const float4*>(hal + aoff[a] + tapoff);
+                    }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // rotate through the accumulators so that consecutive MFMAs are independent
+#define SIV_MFMA_STEP(F)                                                                          \
+    _Pragma("unroll") for (int a = 0; a < C::AM; ++a)                                             \
+    _Pragma("unroll") for (int bb = 0; bb < C::AN; ++bb)                                          \
+        acc[a][bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].F, bv[bb].F, acc[a][bb], 0, 0, 0);
+            SIV_MFMA_STEP(x)
+            SIV_MFMA_STEP(y)
+            SIV_MFMA_STEP(z)
+            SIV_MFMA_STEP(w)
+#undef SIV_MFMA_STEP
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -151,43 +193,46 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
     }
 }
 
-// wt[ci][27 - 1 - tap][co] = w[co][tap][ci]: the weights of the convolution that maps dy to dx
-__global__ __launch_bounds__(256) void k3_flip_transpose(const float* __restrict__ w,
-                                                         float* __restrict__ wt, int Cin, int Cout) {
-    const long total = (long)Cout * 27 * Cin;
+// Pack weights for k3_fwd_mfma: wp[ct][cc][tap][co(64)][ci(8)].
+//   flip == 0 (forward):  kernel (co, ci, tap) reads w[co][tap][ci]              (w is [Kout][27][Kin])
+//   flip == 1 (dgrad):    kernel (co, ci, tap) reads w[ci][26 - tap][co]         (w is [Kin][27][Kout])
+// Kin / Kout are the kernel's input / output channel counts.
+__global__ __launch_bounds__(256) void k3_pack_weights(const float* __restrict__ w,
+                                                       float* __restrict__ wp, int Kin, int Kout,
+                                                       int flip) {
+    const long total = (long)Kout * 27 * Kin;
+    const int nchunk = Kin / 8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(i % Cout);
-        const int tap = (int)((i / Cout) % 27);
-        const int ci = (int)(i / ((long)Cout * 27));
-        wt[i] = w[((long)co * 27 + (26 - tap)) * Cin + ci];
+        const int j = (int)(i & 7);
+        const int co = (int)((i >> 3) & 63);
+        long r = i >> 9;
+        const int tap = (int)(r % 27); r /= 27;
+        const int cc = (int)(r % nchunk);
+        const int ct = (int)(r / nchunk);
+        const int kco = ct * 64 + co, kci = cc * 8 + j;
+        wp[i] = flip ? w[((long)kci * 27 + (26 - tap)) * Kout + kco] : w[((long)kco * 27 + tap) * Kin + kci];
     }
 }
 
-template <int BD, int BH, int BW, int WM, int WN, int CK, int UPS>
-static int launch_fwd(const float* x, const float* w, const float* bias, float* y, int N, int D,
+template <int BD, int BH, int BW, int WM, int WN, int UPS>
+static int launch_fwd(const float* x, const float* wp, const float* bias, float* y, int N, int D,
                       int H, int W, int Cin, int Cout, hipStream_t s) {
-    using C = FwdCfg<BD, BH, BW, WM, WN, CK, UPS>;
+    using C = FwdCfg<BD, BH, BW, WM, WN, UPS>;
     const int nbd = (D + BD - 1) / BD, nbh = (H + BH - 1) / BH, nbw = (W + BW - 1) / BW;
     const long nblk = (long)N * nbd * nbh * nbw;
     if (nblk > 0x7fffffffL) {
         set_error("conv3d_k3(mfma): too many bricks");
         return SIV_EINVAL;
     }
-    auto kern = k3_fwd_mfma<BD, BH, BW, WM, WN, CK, UPS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)C::LDS_BYTES);
-        attr_done = true;
-    }
-    kern<<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 256, C::LDS_BYTES, s>>>(
-        x, w, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
+    k3_fwd_mfma<BD, BH, BW, WM, WN, UPS><<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 256, C::LDS_BYTES, s>>>(
+        x, wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
     SIV_CHECK_LAUNCH("conv3d_k3(mfma)");
     return SIV_OK;
 }
 
 bool k3_fwd_mfma_supported(int Cin, int Cout) { return Cin % 8 == 0 && Cout % 64 == 0; }
+size_t k3_fwd_mfma_ws_bytes(int Cin, int Cout) { return ((size_t)Cout * 27 * Cin + 512) * sizeof(float); }
 
 // Volumes whose bricks would be mostly padding use the small brick.
 static bool use_small_brick(int D, int H, int W) {
@@ -199,24 +244,25 @@ static bool use_small_brick(int D, int H, int W) {
     return waste(2, 4, 8) * 1.15 < waste(4, 8, 8);
 }
 
+// `w` is the convolution's weight tensor; flip selects forward (0) or input-gradient (1) use.
+// Cin / Cout are the channel counts of the tensor the kernel reads / writes.
 int k3_fwd_mfma_launch(const float* x, const float* w, const float* bias, float* y, int N, int D,
-                       int H, int W, int Cin, int Cout, int ups, hipStream_t s) {
-    const bool small = use_small_brick(D, H, W);
-    if (ups == 1) {
-        return small ? launch_fwd<2, 4, 8, 2, 2, 8, 1>(x, w, bias, y, N, D, H, W, Cin, Cout, s)
-                     : launch_fwd<4, 8, 8, 4, 1, 8, 1>(x, w, bias, y, N, D, H, W, Cin, Cout, s);
-    }
-    return small ? launch_fwd<2, 4, 8, 2, 2, 8, 2>(x, w, bias, y, N, D, H, W, Cin, Cout, s)
-                 : launch_fwd<4, 8, 8, 4, 1, 8, 2>(x, w, bias, y, N, D, H, W, Cin, Cout, s);
-}
-
-int k3_flip_transpose_launch(const float* w, float* wt, int Cin, int Cout, hipStream_t s) {
+                       int H, int W, int Cin, int Cout, int ups, int flip, void* ws, size_t ws_bytes,
+                       hipStream_t s) {
+    SIV_CHECK_WS(k3_fwd_mfma_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(mfma)");
+    float* wp = (float*)ws;
     const long total = (long)Cout * 27 * Cin;
     long g = cdiv(total, 256);
     if (g > 4096) g = 4096;
-    k3_flip_transpose<<<(unsigned)g, 256, 0, s>>>(w, wt, Cin, Cout);
-    SIV_CHECK_LAUNCH("conv3d_k3_dgrad(weights)");
-    return SIV_OK;
+    k3_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout, flip);
+    SIV_CHECK_LAUNCH("conv3d_k3(pack weights)");
+    const bool small = use_small_brick(D, H, W);
+    if (ups == 1) {
+        return small ? launch_fwd<2, 4, 8, 2, 2, 1>(x, wp, bias, y, N, D, H, W, Cin, Cout, s)
+                     : launch_fwd<4, 8, 8, 4, 1, 1>(x, wp, bias, y, N, D, H, W, Cin, Cout, s);
+    }
+    return small ? launch_fwd<2, 4, 8, 2, 2, 2>(x, wp, bias, y, N, D, H, W, Cin, Cout, s)
+                 : launch_fwd<4, 8, 8, 4, 1, 2>(x, wp, bias, y, N, D, H, W, Cin, Cout, s);
 }
 
 // ---------------------------------------------------------------------------------
@@ -234,12 +280,72 @@ struct WgCfg {
     static constexpr size_t LDS_BYTES = (size_t)(M * CP + HV * CP) * sizeof(float);
 };
 
+// Global -> register stage of one brick (issued one brick ahead of its use), then register -> LDS.
 template <int UPS>
-__global__ __launch_bounds__(256) void k3_wgrad_mfma(const float* __restrict__ x,
-                                                     const float* __restrict__ dy,
-                                                     float* __restrict__ part, int N, int D, int H,
-                                                     int W, int Cin, int Cout, int nbd, int nbh,
-                                                     int nbw, int bricks_per_block) {
+struct WgStage {
+    using C = WgCfg<UPS>;
+    static constexpr int NDY = C::M * 16 / 256;                 // 4 float4 of dy per thread
+    static constexpr int NX = (C::HV * 16 + 255) / 256;         // 8 float4 of x per thread (last partial)
+    float4 dyr[NDY];
+    float4 xr[NX];
+
+    __device__ __forceinline__ void load(const float* __restrict__ x, const float* __restrict__ dy,
+                                         long br, int kd, int co0, int ci0, int N, int D, int H, int W,
+                                         int Cin, int Cout, int nbd, int nbh, int nbw) {
+        const int tid = threadIdx.x;
+        const int Di = D / UPS, Hi = H / UPS, Wi = W / UPS;
+        long b = br;
+        const int bx = (int)(b % nbw); b /= nbw;
+        const int by = (int)(b % nbh); b /= nbh;
+        const int bz = (int)(b % nbd);
+        const int n = (int)(b / nbd);
+        const int z0 = bz * C::BD, y0 = by * C::BH, x0 = bx * C::BW;
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int idx = tid + 256 * i;
+            const int m = idx >> 4, q = idx & 15;
+            const int gz = z0 + (m >> 5), gy = y0 + ((m >> 3) & 3), gx = x0 + (m & 7);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gz < D && gy < H && gx < W)
+                v = *reinterpret_cast<const float4*>(
+                    dy + ((((long)n * D + gz) * H + gy) * W + gx) * Cout + co0 + 4 * q);
+            dyr[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + 256 * i;
+            const int hv = idx >> 4, q = idx & 15;
+            const int hx = hv % C::HW, hy = (hv / C::HW) % C::HH, hz = hv / (C::HW * C::HH);
+            const int gz = z0 + hz + kd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hv < C::HV && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4*>(
+                    x + ((((long)n * Di + gz / UPS) * Hi + gy / UPS) * Wi + gx / UPS) * Cin + ci0 + 4 * q);
+            xr[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float* dyl, float* xl) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int idx = tid + 256 * i;
+            *reinterpret_cast<float4*>(dyl + (idx >> 4) * C::CP + 4 * (idx & 15)) = dyr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + 256 * i;
+            if ((idx >> 4) < C::HV)
+                *reinterpret_cast<float4*>(xl + (idx >> 4) * C::CP + 4 * (idx & 15)) = xr[i];
+        }
+    }
+};
+
+template <int UPS>
+__global__ __launch_bounds__(256, 2) void k3_wgrad_mfma(const float* __restrict__ x,
+                                                        const float* __restrict__ dy,
+                                                        float* __restrict__ part, int N, int D, int H,
+                                                        int W, int Cin, int Cout, int nbd, int nbh,
+                                                        int nbw, int bricks_per_block) {
     using C = WgCfg<UPS>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dyl = lds;                 // [64 voxels][64 co]
@@ -252,7 +358,6 @@ __global__ __launch_bounds__(256) void k3_wgrad_mfma(const float* __restrict__ x
     const int kd = blockIdx.y;
     const int ntci = Cin / 64;
     const int co0 = (blockIdx.z / ntci) * 64, ci0 = (blockIdx.z % ntci) * 64;
-    const int Di = D / UPS, Hi = H / UPS, Wi = W / UPS;
     const long nbricks = (long)N * nbd * nbh * nbw;
     const long b0 = (long)blockIdx.x * bricks_per_block;
     long b1 = b0 + bricks_per_block;
@@ -264,36 +369,14 @@ __global__ __launch_bounds__(256) void k3_wgrad_mfma(const float* __restrict__ x
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    WgStage<UPS> st;
+    if (b0 < b1) st.load(x, dy, b0, kd, co0, ci0, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
     for (long br = b0; br < b1; ++br) {
-        long b = br;
-        const int bx = (int)(b % nbw); b /= nbw;
-        const int by = (int)(b % nbh); b /= nbh;
-        const int bz = (int)(b % nbd);
-        const int n = (int)(b / nbd);
-        const int z0 = bz * C::BD, y0 = by * C::BH, x0 = bx * C::BW;
+        __syncthreads();              // the previous brick's MFMAs are done with LDS
+        st.store(dyl, xl);
         __syncthreads();
-        // dy tile: 64 voxels x 64 channels = 1024 float4
-        for (int idx = tid; idx < C::M * 16; idx += 256) {
-            const int m = idx >> 4, q = idx & 15;
-            const int gz = z0 + (m >> 5), gy = y0 + ((m >> 3) & 3), gx = x0 + (m & 7);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gz < D && gy < H && gx < W)
-                v = *reinterpret_cast<const float4*>(
-                    dy + ((((long)n * D + gz) * H + gy) * W + gx) * Cout + co0 + 4 * q);
-            *reinterpret_cast<float4*>(dyl + m * C::CP + 4 * q) = v;
-        }
-        // x halo plane for this kd: z in [z0+kd-1, z0+kd-1+BD), y/x with a 1-voxel rim
-        for (int idx = tid; idx < C::HV * 16; idx += 256) {
-            const int hv = idx >> 4, q = idx & 15;
-            const int hx = hv % C::HW, hy = (hv / C::HW) % C::HH, hz = hv / (C::HW * C::HH);
-            const int gz = z0 + hz + kd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4*>(
-                    x + ((((long)n * Di + gz / UPS) * Hi + gy / UPS) * Wi + gx / UPS) * Cin + ci0 + 4 * q);
-            *reinterpret_cast<float4*>(xl + hv * C::CP + 4 * q) = v;
-        }
-        __syncthreads();
+        if (br + 1 < b1)              // next brick's global loads fly during this brick's MFMAs
+            st.load(x, dy, br + 1, kd, co0, ci0, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
         const float* ap = dyl + lh * C::CP + cs * 32 + li;
         const float* bp = xl + lh * C::CP + is * 32 + li;
 #pragma unroll 4
@@ -343,7 +426,10 @@ int k3_wgrad_mfma_launch(const float* x, const float* dy, float* dw, int N, int 
     const int tiles = (Cout / 64) * (Cin / 64);
     // enough blocks to fill the chip twice over, bounded by the workspace
     const long wsize = (long)Cout * 27 * Cin;
-    long nsplit = cdiv(1024, 3L * tiles);
+    // 3*tiles*nsplit blocks at 2 resident blocks per CU: stay at or below a whole number of
+    // rounds (1024 slots = 2 rounds) so that no round runs nearly empty
+    long nsplit = 1024 / (3L * tiles);
+    if (nsplit < 1) nsplit = 1;
     if (nsplit > nbricks) nsplit = nbricks;
     const long max_by_ws = (long)(ws_bytes / (wsize * sizeof(float)));
     if (nsplit > max_by_ws) nsplit = max_by_ws;

@@ -27,8 +27,7 @@ int colsum_launch(const float*, float*, long, int, int, hipStream_t);
 // conv_mfma.hip
 bool k3_fwd_mfma_supported(int Cin, int Cout);
 int k3_fwd_mfma_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int,
-                       int, hipStream_t);
-int k3_flip_transpose_launch(const float*, float*, int, int, hipStream_t);
+                       int, int, void*, size_t, hipStream_t);
 bool k3_wgrad_mfma_supported(int Cin, int Cout);
 int k3_wgrad_mfma_launch(const float*, const float*, float*, int, int, int, int, int, int, int, int,
                          void*, size_t, hipStream_t);
@@ -67,15 +66,14 @@ extern "C" int siv_set_conv_path(int path) {
 extern "C" int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bias, float* y, int N,
                                  int D, int H, int W, int Cin, int Cout, int ups, void* ws,
                                  size_t ws_bytes, siv_stream_t stream) {
-    (void)ws; (void)ws_bytes;
     SIV_CHECK_ARG(x && w && y, "conv3d_k3_fwd: null pointer");
     int rc = check_conv_shape("conv3d_k3_fwd", N, D, H, W, Cin, Cout, ups);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int path = conv_path();
-    const bool al = aligned16(x) && aligned16(w) && aligned16(y);
+    const bool al = aligned16(x) && aligned16(w) && aligned16(y) && aligned16(ws);
     if (path != 1 && al && k3_fwd_mfma_supported(Cin, Cout))
-        return k3_fwd_mfma_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, s);
+        return k3_fwd_mfma_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s);
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
         return k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s);
     SIV_CHECK_ARG(path != 2, "conv3d_k3_fwd: no specialised kernel for Cin=%d Cout=%d ups=%d", Cin,
@@ -93,12 +91,8 @@ extern "C" int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx, i
     const int path = conv_path();
     const bool al = aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws);
     // dgrad is the forward convolution of dy with the flipped, transposed weights
-    if (path != 1 && al && k3_fwd_mfma_supported(Cout, Cin)) {
-        SIV_CHECK_WS((size_t)Cout * 27 * Cin * sizeof(float), ws_bytes, "conv3d_k3_dgrad");
-        rc = k3_flip_transpose_launch(w, (float*)ws, Cin, Cout, s);
-        if (rc) return rc;
-        return k3_fwd_mfma_launch(dy, (const float*)ws, nullptr, dx, N, D, H, W, Cout, Cin, 1, s);
-    }
+    if (path != 1 && al && k3_fwd_mfma_supported(Cout, Cin))
+        return k3_fwd_mfma_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s);
     if (path != 1 && al && k3_thin_supported(Cout, Cin))
         return k3_thin_fwd_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, s);
     SIV_CHECK_ARG(path != 2, "conv3d_k3_dgrad: no specialised kernel for Cin=%d Cout=%d", Cin, Cout);
