@@ -110,16 +110,42 @@ __global__ __launch_bounds__(256) void k3_wgrad_generic(const float* __restrict_
     if (threadIdx.x == 0) dw[e] = accumulate ? dw[e] + acc : acc;
 }
 
-// column sums of a [M][C] matrix: one block per column (bias gradients)
-__global__ __launch_bounds__(256) void colsum_generic(const float* __restrict__ a,
-                                                      float* __restrict__ out, long M, int C,
-                                                      int accumulate) {
-    __shared__ float sh[4];
-    const int c = blockIdx.x;
-    float acc = 0.f;
-    for (long r = threadIdx.x; r < M; r += blockDim.x) acc += a[r * C + c];
-    acc = block_sum_256(acc, sh);
-    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + acc : acc;
+// Column sums of a [M][C] matrix (bias gradients), two deterministic stages: per-block partial
+// rows (threads = (row lane, channel), channel fastest so that a wave reads contiguous memory),
+// then one wave per channel in fp64.
+__global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ a, long M, int C,
+                                                      float* __restrict__ part) {
+    __shared__ float sh[256];
+    const int lanes = C <= 256 ? 256 / C : 1;
+    const long rows_per_block = (M + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+    for (int cb = 0; cb < C; cb += 256) {
+        const int c = cb + (C <= 256 ? (int)(threadIdx.x % C) : (int)threadIdx.x);
+        const int lane = C <= 256 ? (int)(threadIdx.x / C) : 0;
+        float acc = 0.f;
+        if (lane < lanes && c < C)
+            for (long r = r0 + lane; r < r1; r += lanes) acc += a[r * C + c];
+        __syncthreads();
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        if (lane == 0 && c < C) {
+            float t = 0.f;
+            for (int l = 0; l < lanes; ++l) t += sh[C <= 256 ? l * C + (int)(threadIdx.x % C) : (int)threadIdx.x];
+            part[(long)blockIdx.x * C + c] = t;
+        }
+        if (C <= 256) break;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final(const float* __restrict__ part, int nblk, int C,
+                                                    float* __restrict__ out, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = lane; b < nblk; b += 64) s += (double)part[(long)b * C + c];
+    s = wave_sum_d(s);
+    if (lane == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 __global__ __launch_bounds__(256) void upsample2_bwd_k(const float* __restrict__ dy,
@@ -219,21 +245,25 @@ int k3_dgrad_generic_launch(const float* dy, const float* w, float* dx, int N, i
     SIV_CHECK_LAUNCH("conv3d_k3_dgrad(generic)");
     return SIV_OK;
 }
+int colsum_launch(const float* a, float* out, long M, int C, int accumulate, void* ws, size_t ws_bytes,
+                  hipStream_t s) {
+    long nblk = cdiv(M, 64);
+    if (nblk > 1024) nblk = 1024;
+    SIV_CHECK_WS((size_t)nblk * C * sizeof(float), ws_bytes, "bias gradient");
+    colsum_partial<<<(unsigned)nblk, 256, 0, s>>>(a, M, C, (float*)ws);
+    SIV_CHECK_LAUNCH("bias gradient(partial)");
+    colsum_final<<<(C + 3) / 4, 256, 0, s>>>((const float*)ws, (int)nblk, C, out, accumulate);
+    SIV_CHECK_LAUNCH("bias gradient(final)");
+    return SIV_OK;
+}
+
 int k3_wgrad_generic_launch(const float* x, const float* dy, float* dw, float* dbias, int N, int D,
-                            int H, int W, int Cin, int Cout, int ups, int accumulate,
-                            hipStream_t s) {
+                            int H, int W, int Cin, int Cout, int ups, int accumulate, void* ws,
+                            size_t ws_bytes, hipStream_t s) {
     k3_wgrad_generic<<<(unsigned)((long)Cout * 27 * Cin), 256, 0, s>>>(x, dy, dw, N, D, H, W, Cin,
                                                                       Cout, ups, accumulate);
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(generic)");
-    if (dbias) {
-        colsum_generic<<<Cout, 256, 0, s>>>(dy, dbias, (long)N * D * H * W, Cout, accumulate);
-        SIV_CHECK_LAUNCH("conv3d_k3_wgrad(bias)");
-    }
-    return SIV_OK;
-}
-int colsum_launch(const float* a, float* out, long M, int C, int accumulate, hipStream_t s) {
-    colsum_generic<<<C, 256, 0, s>>>(a, out, M, C, accumulate);
-    SIV_CHECK_LAUNCH("colsum");
+    if (dbias) return colsum_launch(dy, dbias, (long)N * D * H * W, Cout, accumulate, ws, ws_bytes, s);
     return SIV_OK;
 }
 
@@ -273,11 +303,10 @@ extern "C" int siv_conv1x1_dgrad(const float* dy, const float* w, float* dx, lon
 extern "C" int siv_conv1x1_wgrad(const float* x, const float* dy, float* dw, float* dbias, long M,
                                  int Cin, int Cout, int accumulate, void* ws, size_t ws_bytes,
                                  siv_stream_t stream) {
-    (void)ws; (void)ws_bytes;
     SIV_CHECK_ARG(x && dy && dw, "conv1x1_wgrad: null pointer");
     SIV_CHECK_ARG(M > 0 && Cin > 0 && Cout > 0, "conv1x1_wgrad: bad shape");
     c1_wgrad_generic<<<Cin * Cout, 256, 0, (hipStream_t)stream>>>(x, dy, dw, M, Cin, Cout, accumulate);
     SIV_CHECK_LAUNCH("conv1x1_wgrad");
-    if (dbias) return colsum_launch(dy, dbias, M, Cout, accumulate, (hipStream_t)stream);
+    if (dbias) return colsum_launch(dy, dbias, M, Cout, accumulate, ws, ws_bytes, (hipStream_t)stream);
     return SIV_OK;
 }

@@ -32,12 +32,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // reads with one coalesced 16-byte load per lane, straight into registers and one tap ahead
 // of its use.  Only the input halo goes through LDS: one barrier pair per 8-channel chunk
 // (27 taps = 432 MFMAs per wave) instead of one per weight slice.
-template <int BD, int BH, int BW, int WM, int WN, int UPS>
+template <int BD, int BH, int BW, int WM, int WN, int NT, int UPS>
 struct FwdCfg {
     static constexpr int CK = 8;               // input channels per chunk
     static constexpr int M = BD * BH * BW;
     static constexpr int MS = M / 32;          // 32-row sub-tiles in the brick
-    static constexpr int NS = 2;               // 64 output channels per block
+    static constexpr int NS = NT / 32;         // NT (32 or 64) output channels per block
+    static constexpr int SLICE = NT * 8;       // floats of one packed (chunk, tap) weight slice
     static constexpr int AM = MS / WM;         // accumulators per wave along M
     static constexpr int AN = NS / WN;
     static constexpr int HD = BD + 2, HH = BH + 2, HW = BW + 2;
@@ -48,13 +49,13 @@ struct FwdCfg {
     static_assert(M % 32 == 0 && MS % WM == 0 && NS % WN == 0 && WM * WN == 4, "bad tiling");
 };
 
-template <int BD, int BH, int BW, int WM, int WN, int UPS>
+template <int BD, int BH, int BW, int WM, int WN, int NT, int UPS>
 __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
                                                    const float* __restrict__ wp,
                                                    const float* __restrict__ bias,
                                                    float* __restrict__ y, int N, int D, int H, int W,
                                                    int Cin, int Cout, int nbd, int nbh, int nbw) {
-    using C = FwdCfg<BD, BH, BW, WM, WN, UPS>;
+    using C = FwdCfg<BD, BH, BW, WM, WN, NT, UPS>;
     extern __shared__ __attribute__((aligned(16))) float hal[];
 
     const int tid = threadIdx.x;
@@ -68,9 +69,9 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
     const int bz = b % nbd;
     const int n = b / nbd;
     const int z0 = bz * BD, y0 = by * BH, x0 = bx * BW;
-    const int co0 = blockIdx.y * 64;
+    const int co0 = blockIdx.y * NT;
     const int Di = D / UPS, Hi = H / UPS, Wi = W / UPS;
-    const int nchunk = Cin / C::CK;
+    const int nchunk = (Cin + C::CK - 1) / C::CK;
 
     f32x16 acc[C::AM][C::AN];
 #pragma unroll
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
         aoff[a] = ((dz * C::HH + dy) * C::HW + dx) * C::CKP + 4 * lh;
     }
     // this lane's B fragment inside a packed [64][8] tap slice: co = (wn*AN + bb)*32 + li, ci 4*lh..
-    const float* wlane = wp + (long)blockIdx.y * nchunk * 27 * 512 + (wn * C::AN * 32 + li) * 8 + 4 * lh;
+    const float* wlane = wp + (long)blockIdx.y * nchunk * 27 * C::SLICE + (wn * C::AN * 32 + li) * 8 + 4 * lh;
 
     float4 bnext[C::AN];
 #pragma unroll
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
             const int hx = hv % C::HW, hy = (hv / C::HW) % C::HH, hz = hv / (C::HW * C::HH);
             const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!(SIV_EXP & 4) && hv < C::HV && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            if (!(SIV_EXP & 4) && hv < C::HV && c0 + 4 * q < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H &&
+                gx >= 0 && gx < W) {
                 const long off =
                     ((((long)n * Di + gz / UPS) * Hi + gy / UPS) * Wi + gx / UPS) * Cin + c0 + 4 * q;
                 v = *reinterpret_cast<const float4*>(x + off);
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
         }
         __syncthreads();
         if (cc + 1 < nchunk) load_halo((cc + 1) * C::CK);
-        const float* wc = wlane + (long)cc * 27 * 512;
+        const float* wc = wlane + (long)cc * 27 * C::SLICE;
         // A fragments are read one tap ahead of their MFMAs as well, so that neither the LDS
         // nor the weight loads are waited for right after they are issued
         float4 anext[C::AM];
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
             // the packed buffer carries one slice of padding so that this never leaves it)
 #pragma unroll
             for (int bb = 0; bb < C::AN; ++bb)
-                if (!(SIV_EXP & 1)) bnext[bb] = *reinterpret_cast<const float4*>(wc + (t + 1) * 512 + bb * 256);
+                if (!(SIV_EXP & 1)) bnext[bb] = *reinterpret_cast<const float4*>(wc + (t + 1) * C::SLICE + bb * 256);
             if (t + 1 < 27) {
                 const int t1 = t + 1;
                 const int tapoff = (((t1 / 9) * C::HH + (t1 / 3) % 3) * C::HW + t1 % 3) * C::CKP;
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
 #pragma unroll
     for (int bb = 0; bb < C::AN; ++bb) {
         const int co = co0 + (wn * C::AN + bb) * 32 + li;
+        if (co >= Cout) continue;
         const float bv = bias ? bias[co] : 0.f;
 #pragma unroll
         for (int a = 0; a < C::AM; ++a) {
@@ -193,46 +196,56 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
     }
 }
 
-// Pack weights for k3_fwd_mfma: wp[ct][cc][tap][co(64)][ci(8)].
+// Pack weights for k3_fwd_mfma: wp[ct][cc][tap][co (NT)][ci (8)], zero padded to whole tiles/chunks.
 //   flip == 0 (forward):  kernel (co, ci, tap) reads w[co][tap][ci]              (w is [Kout][27][Kin])
 //   flip == 1 (dgrad):    kernel (co, ci, tap) reads w[ci][26 - tap][co]         (w is [Kin][27][Kout])
 // Kin / Kout are the kernel's input / output channel counts.
 __global__ __launch_bounds__(256) void k3_pack_weights(const float* __restrict__ w,
                                                        float* __restrict__ wp, int Kin, int Kout,
-                                                       int flip) {
-    const long total = (long)Kout * 27 * Kin;
-    const int nchunk = Kin / 8;
+                                                       int NT, int flip) {
+    const int nchunk = (Kin + 7) / 8, ntile = (Kout + NT - 1) / NT;
+    const long total = (long)ntile * nchunk * 27 * NT * 8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long)gridDim.x * blockDim.x) {
         const int j = (int)(i & 7);
-        const int co = (int)((i >> 3) & 63);
-        long r = i >> 9;
+        long r = i >> 3;
+        const int co = (int)(r % NT); r /= NT;
         const int tap = (int)(r % 27); r /= 27;
         const int cc = (int)(r % nchunk);
         const int ct = (int)(r / nchunk);
-        const int kco = ct * 64 + co, kci = cc * 8 + j;
-        wp[i] = flip ? w[((long)kci * 27 + (26 - tap)) * Kout + kco] : w[((long)kco * 27 + tap) * Kin + kci];
+        const int kco = ct * NT + co, kci = cc * 8 + j;
+        float v = 0.f;
+        if (kco < Kout && kci < Kin)
+            v = flip ? w[((long)kci * 27 + (26 - tap)) * Kout + kco] : w[((long)kco * 27 + tap) * Kin + kci];
+        wp[i] = v;
     }
 }
 
-template <int BD, int BH, int BW, int WM, int WN, int UPS>
+template <int BD, int BH, int BW, int WM, int WN, int NT, int UPS>
 static int launch_fwd(const float* x, const float* wp, const float* bias, float* y, int N, int D,
                       int H, int W, int Cin, int Cout, hipStream_t s) {
-    using C = FwdCfg<BD, BH, BW, WM, WN, UPS>;
+    using C = FwdCfg<BD, BH, BW, WM, WN, NT, UPS>;
     const int nbd = (D + BD - 1) / BD, nbh = (H + BH - 1) / BH, nbw = (W + BW - 1) / BW;
     const long nblk = (long)N * nbd * nbh * nbw;
     if (nblk > 0x7fffffffL) {
         set_error("conv3d_k3(mfma): too many bricks");
         return SIV_EINVAL;
     }
-    k3_fwd_mfma<BD, BH, BW, WM, WN, UPS><<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 256, C::LDS_BYTES, s>>>(
-        x, wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
+    k3_fwd_mfma<BD, BH, BW, WM, WN, NT, UPS>
+        <<<dim3((unsigned)nblk, (unsigned)((Cout + NT - 1) / NT)), 256, C::LDS_BYTES, s>>>(
+            x, wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
     SIV_CHECK_LAUNCH("conv3d_k3(mfma)");
     return SIV_OK;
 }
 
-bool k3_fwd_mfma_supported(int Cin, int Cout) { return Cin % 8 == 0 && Cout % 64 == 0; }
-size_t k3_fwd_mfma_ws_bytes(int Cin, int Cout) { return ((size_t)Cout * 27 * Cin + 512) * sizeof(float); }
+// Channel counts the matrix-core path takes: 16-byte channel groups on the input side, anything
+// on the output side (tiles of 32 or 64 output channels, zero padded).
+bool k3_fwd_mfma_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cin >= 4 && Cout >= 8; }
+static int fwd_tile(int Cout) { return Cout % 64 == 0 ? 64 : 32; }
+size_t k3_fwd_mfma_ws_bytes(int Cin, int Cout) {
+    const int NT = fwd_tile(Cout);
+    return ((size_t)((Cout + NT - 1) / NT) * ((Cin + 7) / 8) * 27 * NT * 8 + 512) * sizeof(float);
+}
 
 // Volumes whose bricks would be mostly padding use the small brick.
 static bool use_small_brick(int D, int H, int W) {
@@ -251,18 +264,19 @@ int k3_fwd_mfma_launch(const float* x, const float* w, const float* bias, float*
                        hipStream_t s) {
     SIV_CHECK_WS(k3_fwd_mfma_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(mfma)");
     float* wp = (float*)ws;
-    const long total = (long)Cout * 27 * Cin;
+    const int NT = fwd_tile(Cout);
+    const long total = (long)((Cout + NT - 1) / NT) * ((Cin + 7) / 8) * 27 * NT * 8;
     long g = cdiv(total, 256);
     if (g > 4096) g = 4096;
-    k3_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout, flip);
+    k3_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout, NT, flip);
     SIV_CHECK_LAUNCH("conv3d_k3(pack weights)");
-    const bool small = use_small_brick(D, H, W);
-    if (ups == 1) {
-        return small ? launch_fwd<2, 4, 8, 2, 2, 1>(x, wp, bias, y, N, D, H, W, Cin, Cout, s)
-                     : launch_fwd<4, 8, 8, 4, 1, 1>(x, wp, bias, y, N, D, H, W, Cin, Cout, s);
-    }
-    return small ? launch_fwd<2, 4, 8, 2, 2, 2>(x, wp, bias, y, N, D, H, W, Cin, Cout, s)
-                 : launch_fwd<4, 8, 8, 4, 1, 2>(x, wp, bias, y, N, D, H, W, Cin, Cout, s);
+    const bool small = NT == 64 && use_small_brick(D, H, W);
+#define SIV_FWD(BD, BH, BW, WM, WN, NTT)                                                              \
+    (ups == 1 ? launch_fwd<BD, BH, BW, WM, WN, NTT, 1>(x, wp, bias, y, N, D, H, W, Cin, Cout, s)       \
+              : launch_fwd<BD, BH, BW, WM, WN, NTT, 2>(x, wp, bias, y, N, D, H, W, Cin, Cout, s))
+    if (NT == 32) return SIV_FWD(4, 8, 8, 4, 1, 32);
+    return small ? SIV_FWD(2, 4, 8, 2, 2, 64) : SIV_FWD(4, 8, 8, 4, 1, 64);
+#undef SIV_FWD
 }
 
 // ---------------------------------------------------------------------------------
@@ -306,7 +320,7 @@ struct WgStage {
             const int m = idx >> 4, q = idx & 15;
             const int gz = z0 + (m >> 5), gy = y0 + ((m >> 3) & 3), gx = x0 + (m & 7);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gz < D && gy < H && gx < W)
+            if (gz < D && gy < H && gx < W && co0 + 4 * q < Cout)
                 v = *reinterpret_cast<const float4*>(
                     dy + ((((long)n * D + gz) * H + gy) * W + gx) * Cout + co0 + 4 * q);
             dyr[i] = v;
@@ -318,7 +332,8 @@ struct WgStage {
             const int hx = hv % C::HW, hy = (hv / C::HW) % C::HH, hz = hv / (C::HW * C::HH);
             const int gz = z0 + hz + kd - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hv < C::HV && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W)
+            if (hv < C::HV && ci0 + 4 * q < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 &&
+                gx < W)
                 v = *reinterpret_cast<const float4*>(
                     x + ((((long)n * Di + gz / UPS) * Hi + gy / UPS) * Wi + gx / UPS) * Cin + ci0 + 4 * q);
             xr[i] = v;
@@ -356,8 +371,10 @@ __global__ __launch_bounds__(256, 2) void k3_wgrad_mfma(const float* __restrict_
     const int li = lane & 31, lh = lane >> 5;
     const int cs = wave & 1, is = wave >> 1;
     const int kd = blockIdx.y;
-    const int ntci = Cin / 64;
+    const int ntci = (Cin + 63) / 64;
     const int co0 = (blockIdx.z / ntci) * 64, ci0 = (blockIdx.z % ntci) * 64;
+    // a wave whose 32x32 (co, ci) sub-tile lies outside the channel ranges only helps staging
+    const bool active = co0 + cs * 32 < Cout && ci0 + is * 32 < Cin;
     const long nbricks = (long)N * nbd * nbh * nbw;
     const long b0 = (long)blockIdx.x * bricks_per_block;
     long b1 = b0 + bricks_per_block;
@@ -379,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void k3_wgrad_mfma(const float* __restrict_
             st.load(x, dy, br + 1, kd, co0, ci0, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
         const float* ap = dyl + lh * C::CP + cs * 32 + li;
         const float* bp = xl + lh * C::CP + is * 32 + li;
+        if (active)
 #pragma unroll 4
         for (int kk = 0; kk < 32; ++kk) {
             // voxels 2kk + lh: dx = 2*(kk&3) + lh, dy = (kk>>2)&3, dz = kk>>4
@@ -400,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void k3_wgrad_mfma(const float* __restrict_
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + cs * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int ci = ci0 + is * 32 + li;
-            pp[((long)co * 27 + kd * 9 + t) * Cin + ci] = acc[t][r];
+            if (co < Cout && ci < Cin) pp[((long)co * 27 + kd * 9 + t) * Cin + ci] = acc[t][r];
         }
     }
 }
@@ -416,14 +434,16 @@ __global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ par
     }
 }
 
-bool k3_wgrad_mfma_supported(int Cin, int Cout) { return Cin % 64 == 0 && Cout % 64 == 0; }
+bool k3_wgrad_mfma_supported(int Cin, int Cout) {
+    return Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 4 && Cout >= 8;
+}
 
 int k3_wgrad_mfma_launch(const float* x, const float* dy, float* dw, int N, int D, int H, int W,
                          int Cin, int Cout, int ups, int accumulate, void* ws, size_t ws_bytes,
                          hipStream_t s) {
     const int nbd = (D + 1) / 2, nbh = (H + 3) / 4, nbw = (W + 7) / 8;
     const long nbricks = (long)N * nbd * nbh * nbw;
-    const int tiles = (Cout / 64) * (Cin / 64);
+    const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     // enough blocks to fill the chip twice over, bounded by the workspace
     const long wsize = (long)Cout * 27 * Cin;
     // 3*tiles*nsplit blocks at 2 resident blocks per CU: stay at or below a whole number of

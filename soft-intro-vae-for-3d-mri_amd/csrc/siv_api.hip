@@ -22,8 +22,8 @@ int k3_fwd_generic_launch(const float*, const float*, const float*, float*, int,
 int k3_dgrad_generic_launch(const float*, const float*, float*, int, int, int, int, int, int,
                             hipStream_t);
 int k3_wgrad_generic_launch(const float*, const float*, float*, float*, int, int, int, int, int, int,
-                            int, int, hipStream_t);
-int colsum_launch(const float*, float*, long, int, int, hipStream_t);
+                            int, int, void*, size_t, hipStream_t);
+int colsum_launch(const float*, float*, long, int, int, void*, size_t, hipStream_t);
 // conv_mfma.hip
 bool k3_fwd_mfma_supported(int Cin, int Cout);
 int k3_fwd_mfma_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int,
@@ -72,10 +72,10 @@ extern "C" int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bi
     hipStream_t s = (hipStream_t)stream;
     const int path = conv_path();
     const bool al = aligned16(x) && aligned16(w) && aligned16(y) && aligned16(ws);
-    if (path != 1 && al && k3_fwd_mfma_supported(Cin, Cout))
-        return k3_fwd_mfma_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s);
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
         return k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s);
+    if (path != 1 && al && k3_fwd_mfma_supported(Cin, Cout))
+        return k3_fwd_mfma_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s);
     SIV_CHECK_ARG(path != 2, "conv3d_k3_fwd: no specialised kernel for Cin=%d Cout=%d ups=%d", Cin,
                   Cout, ups);
     return k3_fwd_generic_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, s);
@@ -91,10 +91,10 @@ extern "C" int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx, i
     const int path = conv_path();
     const bool al = aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws);
     // dgrad is the forward convolution of dy with the flipped, transposed weights
-    if (path != 1 && al && k3_fwd_mfma_supported(Cout, Cin))
-        return k3_fwd_mfma_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s);
     if (path != 1 && al && k3_thin_supported(Cout, Cin))
         return k3_thin_fwd_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, s);
+    if (path != 1 && al && k3_fwd_mfma_supported(Cout, Cin))
+        return k3_fwd_mfma_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s);
     SIV_CHECK_ARG(path != 2, "conv3d_k3_dgrad: no specialised kernel for Cin=%d Cout=%d", Cin, Cout);
     return k3_dgrad_generic_launch(dy, w, dx, N, D, H, W, Cin, Cout, s);
 }
@@ -108,15 +108,15 @@ extern "C" int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, f
     hipStream_t s = (hipStream_t)stream;
     const int path = conv_path();
     const bool al = aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(ws);
+    if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
+        return k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
     if (path != 1 && al && k3_wgrad_mfma_supported(Cin, Cout)) {
         rc = k3_wgrad_mfma_launch(x, dy, dw, N, D, H, W, Cin, Cout, ups, accumulate, ws, ws_bytes, s);
         if (rc) return rc;
-        if (dbias) return colsum_launch(dy, dbias, (long)N * D * H * W, Cout, accumulate, s);
+        if (dbias) return colsum_launch(dy, dbias, (long)N * D * H * W, Cout, accumulate, ws, ws_bytes, s);
         return SIV_OK;
     }
-    if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
-        return k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
     SIV_CHECK_ARG(path != 2, "conv3d_k3_wgrad: no specialised kernel for Cin=%d Cout=%d ups=%d", Cin,
                   Cout, ups);
-    return k3_wgrad_generic_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, ups, accumulate, s);
+    return k3_wgrad_generic_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, ups, accumulate, ws, ws_bytes, s);
 }

@@ -66,6 +66,11 @@ CONV_CASES = [
     (16, 128, (10, 12, 10), 2, 1, 0), (128, 64, (4, 8, 8), 1, 1, 0), (64, 128, (3, 5, 17), 1, 1, 0),
     (64, 64, (8, 12, 8), 2, 2, 0), (128, 64, (8, 8, 16), 1, 2, 0), (256, 256, (2, 4, 8), 1, 1, 0),
     (64, 64, (16, 16, 16), 1, 1, 0),
+    # channel counts that are not multiples of the 8-channel chunk / 32-64-channel tiles
+    # (vae_main.py's 12-24-32-48 and 600z_main.py's 16-32-64-128 widths)
+    (12, 24, (8, 12, 8), 2, 1, 0), (16, 16, (9, 10, 11), 1, 1, 0), (24, 12, (8, 12, 8), 1, 2, 0),
+    (48, 32, (4, 8, 8), 2, 1, 0), (32, 48, (5, 6, 5), 3, 1, 0), (128, 16, (4, 8, 8), 1, 1, 0),
+    (4, 8, (8, 8, 8), 1, 1, 0), (20, 100, (4, 4, 8), 1, 1, 0),
     # the same wide shapes through the generic kernels (cross-check of the dispatcher)
     (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
 ]
