@@ -81,6 +81,24 @@ int siv_conv1x1_wgrad(const float* x, const float* dy, float* dw, float* dbias,
                       long M, int Cin, int Cout, int accumulate,
                       void* ws, size_t ws_bytes, siv_stream_t stream);
 
+/* ---- fully connected layers of the FC-latent model ---------------------------------
+ * y[b][o] = bias[o] + sum_k x[b][k] w[o][k]: nn.Linear of models/mymodel.py:125 (encoder
+ * head, K = forth_ch*150, O = 2*z) and :151 (decoder stem, K = z, O = forth_ch*150).
+ * x is [B][K] row-major in the reference's flatten order (channel-major), w is [O][K]. */
+int siv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int O,
+                   siv_stream_t stream);
+int siv_linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int O,
+                     void* ws, size_t ws_bytes, siv_stream_t stream);
+int siv_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, int B, int K, int O,
+                     int accumulate, siv_stream_t stream);
+/* out = LeakyReLU_slope(a + b): the skip connections `self.Leakyrelu5(x + h)` etc. of
+ * models/mymodel.py:136,139,222,225; backward d = dout * act'(a + b) is the gradient of both
+ * a and b. */
+int siv_add_act_fwd(const float* a, const float* b, float slope, float* out, long n,
+                    siv_stream_t stream);
+int siv_add_act_bwd(const float* dout, const float* a, const float* b, float slope, float* d,
+                    long n, siv_stream_t stream);
+
 /* ---- BatchNorm3d (+ residual + activation + AvgPool3d + Dropout) ----------------
  * siv_bn_stats: training-mode batch statistics of nn.BatchNorm3d (models/models.py:18,22,
  * 56,60,93,119): per-channel mean and BIASED variance over the M = N*D*H*W rows of y,

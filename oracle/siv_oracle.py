@@ -134,6 +134,18 @@ class Cfg:
         return self.block_setting[-1][0]
 
 
+class FcCfg:
+    """The FC-latent model of models/mymodel.py: SoftIntroVAE(first_ch, second_ch, third_ch,
+    forth_ch, z_ch).  LeakyReLU(0.2) everywhere, no dropout, biased convolutions, a Linear
+    head/stem around a forth_ch x 5 x 6 x 5 bottleneck (input must be 80 x 96 x 80)."""
+
+    slope = 0.2
+
+    def __init__(self, first_ch: int, second_ch: int, third_ch: int, forth_ch: int, z_ch: int):
+        self.ch = (first_ch, second_ch, third_ch, forth_ch)
+        self.z_ch = z_ch
+
+
 # --------------------------------------------------------------------------
 # layers
 # --------------------------------------------------------------------------
@@ -190,9 +202,64 @@ def upsample_block(x: Tensor, sd: State, p: str, cin: int, cout: int, stride: in
     return act(h, slope)
 
 
-def encode(x: Tensor, sd: State, cfg: Cfg, draws: Optional[Draws], train: bool,
+def _cbl(x: Tensor, sd: State, p: str, i: int, train: bool, slope: Optional[float] = 0.2) -> Tensor:
+    """Entries i, i+1, i+2 of one of models/mymodel.py's Sequentials: biased conv3 -> BN ->
+    LeakyReLU (``slope=None`` stops after the BN, as block7 / decoder block1 / block3 do)."""
+    h = F.conv3d(x, sd[f"{p}{i}.weight"], sd[f"{p}{i}.bias"], 1, 1)
+    h = batchnorm(h, sd, f"{p}{i + 1}.", train)
+    return h if slope is None else act(h, slope)
+
+
+def fc_encode(x: Tensor, sd: State, cfg: FcCfg, train: bool, prefix: str = "encoder.") -> Tuple[Tensor, Tensor]:
+    """ResNetVAEencoder.forward -- models/mymodel.py:127-143."""
+    for b in ("block1.", "block2.", "block3."):                 # :128-133
+        x = _cbl(_cbl(x, sd, prefix + b, 0, train), sd, prefix + b, 3, train)
+        x = F.avg_pool3d(x, 2)
+    x = _cbl(x, sd, prefix + "block4short.", 0, train)          # :134
+    h = _cbl(x, sd, prefix + "block5.", 0, train)               # :135
+    x = act(x + h, cfg.slope)                                   # :136
+    x = _cbl(x, sd, prefix + "block6.", 0, train)               # :137 (conv, BN, act, pool, conv, BN, act)
+    x = F.avg_pool3d(x, 2)
+    x = _cbl(x, sd, prefix + "block6.", 4, train)
+    h = _cbl(x, sd, prefix + "block7.", 0, train)               # :138
+    h = _cbl(h, sd, prefix + "block7.", 3, train, slope=None)
+    x = act(x + h, cfg.slope)                                   # :139
+    x = x.reshape(x.size(0), -1)                                # :140
+    x = F.linear(x, sd[prefix + "fc.weight"], sd[prefix + "fc.bias"])
+    mu, logvar = x.chunk(2, dim=1)                              # :142
+    return mu, logvar
+
+
+def fc_decode(z: Tensor, sd: State, cfg: FcCfg, train: bool, prefix: str = "decoder.") -> Tensor:
+    """ResNetDecoder.forward -- models/mymodel.py:217-230."""
+    def up(y, b):                                               # conv, BN, act, Upsample(2), conv, BN, act
+        y = _cbl(y, sd, prefix + b, 0, train)
+        y = F.interpolate(y, scale_factor=2, mode="nearest")
+        return _cbl(y, sd, prefix + b, 4, train)
+
+    def res(y, b):                                              # LeakyReLU(y + [conv, BN, act, conv, BN](y))
+        h = _cbl(y, sd, prefix + b, 0, train)
+        h = _cbl(h, sd, prefix + b, 3, train, slope=None)
+        return act(y + h, cfg.slope)
+
+    y = z.reshape(z.size(0), -1)
+    y = F.relu(F.linear(y, sd[prefix + "dfc.0.weight"], sd[prefix + "dfc.0.bias"]))   # :219
+    y = y.reshape(y.size(0), cfg.ch[3], 5, 6, 5)                # :220
+    y = res(y, "block1.")                                       # :221-222
+    y = up(y, "block2u.")
+    y = res(y, "block3.")                                       # :224-225
+    y = up(y, "block4u.")
+    y = up(y, "block5u.")
+    y = up(y, "block6u.")
+    return F.relu(F.conv3d(y, sd[prefix + "last_block.0.weight"], sd[prefix + "last_block.0.bias"], 1, 1))
+
+
+def encode(x: Tensor, sd: State, cfg, draws: Optional[Draws], train: bool,
            prefix: str = "encoder.") -> Tuple[Tensor, Tensor]:
-    """VAEResNetEncoder.forward -- models/models.py:83-108, 213-223."""
+    """VAEResNetEncoder.forward -- models/models.py:83-108, 213-223 (``FcCfg`` selects
+    models/mymodel.py's encoder instead)."""
+    if isinstance(cfg, FcCfg):
+        return fc_encode(x, sd, cfg, train, prefix)
     p = prefix + "blocks.0."
     h = F.conv3d(x, sd[p + "0.weight"], sd[p + "0.bias"], 1, 1)
     h = batchnorm(h, sd, p + "1.", train)
@@ -205,9 +272,11 @@ def encode(x: Tensor, sd: State, cfg: Cfg, draws: Optional[Draws], train: bool,
     return mu, logvar
 
 
-def decode(z: Tensor, sd: State, cfg: Cfg, draws: Optional[Draws], train: bool,
+def decode(z: Tensor, sd: State, cfg, draws: Optional[Draws], train: bool,
            prefix: str = "decoder.") -> Tensor:
-    """ResNetDecoder.forward -- models/models.py:110-145."""
+    """ResNetDecoder.forward -- models/models.py:110-145 (``FcCfg``: models/mymodel.py's)."""
+    if isinstance(cfg, FcCfg):
+        return fc_decode(z, sd, cfg, train, prefix)
     p = prefix + "blocks.0."
     h = F.conv3d(z, sd[p + "0.weight"], sd[p + "0.bias"])
     h = batchnorm(h, sd, p + "1.", train)

@@ -18,8 +18,14 @@ CL3D = torch.channels_last_3d
 
 
 def cl(t: torch.Tensor) -> torch.Tensor:
-    """NDHWC memory for a logical NCDHW tensor (no copy when already so)."""
-    return t.contiguous(memory_format=CL3D)
+    """NDHWC memory for a logical NCDHW tensor (no copy when already so); tensors of any other
+    rank (the (B, z) latent vectors of the FC-latent model) are made row-major."""
+    return t.contiguous(memory_format=CL3D) if t.dim() == 5 else t.contiguous()
+
+
+def like(t: torch.Tensor) -> torch.Tensor:
+    """Uninitialised tensor with the shape of ``t`` and the memory layout ``cl`` gives it."""
+    return torch.empty_like(t, memory_format=CL3D if t.dim() == 5 else torch.contiguous_format)
 
 
 def empty_cl(shape, like: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
@@ -140,6 +146,57 @@ class HipBackend:
                                               ws, wsb, self._stream(dy)), "siv_conv1x1_wgrad")
         return dw, db
 
+    # ---- fully connected layers ------------------------------------------------------
+    def linear_fwd(self, x, w, bias):
+        self._check_dev(x, w, bias)
+        x, w = x.contiguous(), w.contiguous()
+        B, K = x.shape
+        O = w.shape[0]
+        assert w.shape[1] == K, (tuple(w.shape), K)
+        y = torch.empty((B, O), device=x.device, dtype=torch.float32)
+        _lib.check(self.lib.siv_linear_fwd(_p(x), _p(w), _p(bias), _p(y), B, K, O, self._stream(x)),
+                   "siv_linear_fwd")
+        return y
+
+    def linear_dgrad(self, dy, w):
+        self._check_dev(dy, w)
+        dy, w = dy.contiguous(), w.contiguous()
+        B, O = dy.shape
+        K = w.shape[1]
+        dx = torch.empty((B, K), device=dy.device, dtype=torch.float32)
+        ws, wsb = self._workspace(dy)
+        _lib.check(self.lib.siv_linear_dgrad(_p(dy), _p(w), _p(dx), B, K, O, ws, wsb, self._stream(dy)),
+                   "siv_linear_dgrad")
+        return dx
+
+    def linear_wgrad(self, x, dy, want_bias: bool = False):
+        self._check_dev(x, dy)
+        x, dy = x.contiguous(), dy.contiguous()
+        B, K = x.shape
+        O = dy.shape[1]
+        dw = torch.empty((O, K), device=dy.device, dtype=torch.float32)
+        db = torch.empty(O, device=dy.device, dtype=torch.float32) if want_bias else None
+        _lib.check(self.lib.siv_linear_wgrad(_p(x), _p(dy), _p(dw), _p(db), B, K, O, 0, self._stream(dy)),
+                   "siv_linear_wgrad")
+        return dw, db
+
+    def add_act_fwd(self, a, b, slope):
+        self._check_dev(a, b)
+        a, b = cl(a), cl(b)
+        assert a.shape == b.shape, (a.shape, b.shape)
+        out = like(a)
+        _lib.check(self.lib.siv_add_act_fwd(_p(a), _p(b), float(slope), _p(out), a.numel(), self._stream(a)),
+                   "siv_add_act_fwd")
+        return out
+
+    def add_act_bwd(self, dout, a, b, slope):
+        self._check_dev(dout, a, b)
+        dout, a, b = cl(dout), cl(a), cl(b)
+        d = like(a)
+        _lib.check(self.lib.siv_add_act_bwd(_p(dout), _p(a), _p(b), float(slope), _p(d), a.numel(),
+                                            self._stream(a)), "siv_add_act_bwd")
+        return d
+
     # ---- batch norm + activation tail --------------------------------------------
     def bn_stats(self, y, running_mean, running_var, nbt, momentum: float):
         self._check_dev(y, running_mean, running_var, nbt)
@@ -174,10 +231,10 @@ class HipBackend:
         res = cl(res) if res is not None else None
         keep = cl(keep) if keep is not None else None
         N, C, D, H, W = y.shape
-        dy = torch.empty_like(y, memory_format=CL3D)
+        dy = like(y)
         dgamma = torch.empty(C, device=y.device, dtype=torch.float32) if want_affine else None
         dbeta = torch.empty(C, device=y.device, dtype=torch.float32) if want_affine else None
-        dres = torch.empty_like(y, memory_format=CL3D) if (want_res and res is not None) else None
+        dres = like(y) if (want_res and res is not None) else None
         ws, wsb = self._workspace(y)
         _lib.check(self.lib.siv_bn_act_bwd(_p(dout), _p(y), _p(mean), _p(var), _p(gamma), _p(beta), _p(res),
                                            _p(keep), float(p), float(slope), int(pool), float(eps),
@@ -189,7 +246,7 @@ class HipBackend:
         self._check_dev(x, keep)
         x = cl(x)
         keep = cl(keep) if keep is not None else None
-        out = torch.empty_like(x, memory_format=CL3D)
+        out = like(x)
         _lib.check(self.lib.siv_act_dropout_fwd(_p(x), _p(keep), float(p), float(slope), _p(out), x.numel(),
                                                 self._stream(x)), "siv_act_dropout_fwd")
         return out
@@ -198,7 +255,7 @@ class HipBackend:
         self._check_dev(dout, x, keep)
         dout, x = cl(dout), cl(x)
         keep = cl(keep) if keep is not None else None
-        dx = torch.empty_like(x, memory_format=CL3D)
+        dx = like(x)
         _lib.check(self.lib.siv_act_dropout_bwd(_p(dout), _p(x), _p(keep), float(p), float(slope), _p(dx),
                                                 x.numel(), self._stream(x)), "siv_act_dropout_bwd")
         return dx
@@ -208,7 +265,7 @@ class HipBackend:
         self._check_dev(mu, logvar, eps)
         mu, logvar = cl(mu), cl(logvar)
         eps = cl(eps) if eps is not None else None
-        z = torch.empty_like(mu, memory_format=CL3D)
+        z = like(mu)
         _lib.check(self.lib.siv_reparam_fwd(_p(mu), _p(logvar), _p(eps), float(eps_const), _p(z), mu.numel(),
                                             self._stream(mu)), "siv_reparam_fwd")
         return z
@@ -217,8 +274,8 @@ class HipBackend:
         self._check_dev(dz, logvar, eps)
         dz, logvar = cl(dz), cl(logvar)
         eps = cl(eps) if eps is not None else None
-        dmu = torch.empty_like(dz, memory_format=CL3D)
-        dlv = torch.empty_like(dz, memory_format=CL3D)
+        dmu = like(dz)
+        dlv = like(dz)
         _lib.check(self.lib.siv_reparam_bwd(_p(dz), _p(logvar), _p(eps), float(eps_const), _p(dmu), _p(dlv),
                                             dz.numel(), self._stream(dz)), "siv_reparam_bwd")
         return dmu, dlv
@@ -236,8 +293,8 @@ class HipBackend:
         self._check_dev(g, mu, logvar)
         mu, logvar, g = cl(mu), cl(logvar), g.contiguous()
         B = mu.shape[0]
-        dmu = torch.empty_like(mu, memory_format=CL3D)
-        dlv = torch.empty_like(mu, memory_format=CL3D)
+        dmu = like(mu)
+        dlv = like(mu)
         _lib.check(self.lib.siv_kl_bwd(_p(g), _p(mu), _p(logvar), _p(dmu), _p(dlv), B, mu.numel() // B,
                                        self._stream(mu)), "siv_kl_bwd")
         return dmu, dlv
@@ -257,8 +314,8 @@ class HipBackend:
         self._check_dev(g, x, y)
         x, y, g = cl(x), cl(y), g.contiguous()
         B = x.shape[0]
-        dx = torch.empty_like(x, memory_format=CL3D) if want_x else None
-        dy = torch.empty_like(x, memory_format=CL3D) if want_y else None
+        dx = like(x) if want_x else None
+        dy = like(x) if want_y else None
         _lib.check(self.lib.siv_sse_bwd(_p(g), _p(x), _p(y), _p(dx), _p(dy), B, x.numel() // B,
                                         self._stream(x)), "siv_sse_bwd")
         return dx, dy

@@ -70,6 +70,52 @@ def conv1x1(x, w, bias=None):
     return _Conv1x1.apply(x, w, bias)
 
 
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return get_backend().linear_fwd(x, w, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B = get_backend()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = B.linear_dgrad(dy, w)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            dw, db = B.linear_wgrad(x, dy, want_b)
+            if not ctx.needs_input_grad[1]:
+                dw = None
+        return dx, dw, db
+
+
+def linear(x, w, bias=None):
+    """nn.Linear on a (B, K) input."""
+    return _Linear.apply(x, w, bias)
+
+
+class _AddAct(Function):
+    @staticmethod
+    def forward(ctx, a, b, slope):
+        ctx.save_for_backward(a, b)
+        ctx.slope = slope
+        return get_backend().add_act_fwd(a, b, slope)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b = ctx.saved_tensors
+        d = get_backend().add_act_bwd(dout, a, b, ctx.slope)
+        return (d if ctx.needs_input_grad[0] else None), (d if ctx.needs_input_grad[1] else None), None
+
+
+def add_act(a, b, slope: float):
+    """LeakyReLU(slope)(a + b) -- a skip connection that is not preceded by a BatchNorm."""
+    return _AddAct.apply(a, b, slope)
+
+
 class _BnAct(Function):
     @staticmethod
     def forward(ctx, y, gamma, beta, res, keep, bn, p, slope, pool, train):

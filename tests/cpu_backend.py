@@ -42,6 +42,22 @@ class CpuCheckerBackend:
         dw = nngrad.conv3d_weight(x, (dy.shape[1], x.shape[1], 1, 1, 1), dy)
         return dw, (dy.sum(dim=(0, 2, 3, 4)) if want_bias else None)
 
+    def linear_fwd(self, x, w, bias):
+        return F.linear(x, w, bias)
+
+    def linear_dgrad(self, dy, w):
+        return dy @ w
+
+    def linear_wgrad(self, x, dy, want_bias=False):
+        return dy.t() @ x, (dy.sum(0) if want_bias else None)
+
+    def add_act_fwd(self, a, b, slope):
+        return O.act(a + b, slope)
+
+    def add_act_bwd(self, dout, a, b, slope):
+        s = a + b
+        return dout * torch.where(s > 0, torch.ones_like(s), torch.full_like(s, slope))
+
     def bn_stats(self, y, running_mean, running_var, nbt, momentum):
         mean = y.mean(dim=(0, 2, 3, 4))
         var = y.var(dim=(0, 2, 3, 4), unbiased=False)

@@ -305,3 +305,112 @@ def test_full_size_bn_tail_properties():
     dy, dg, db, _ = B.bn_act_bwd(dout, y, mean, var, ones, zeros, None, None, 0.0, 1.0, 1, 1e-5, True, False)
     assert float(dy.abs().max()) < 1e-5
     assert abs(float(db[0]) - 2 * 80 * 96 * 80) < 1.0
+
+
+# ---------------------------------------------------------------------------------------
+# FC-latent model (models/mymodel.py + utils/trainer_fc.py)
+# ---------------------------------------------------------------------------------------
+def test_g7_fc_model_matches_reference_fixture():
+    """Forward (train + eval) and the first E+D iteration of the narrow FC-latent fixture at the
+    full 80x96x80 extent.  Gradients are compared through float64 truth (tests/fc_truth.py)."""
+    import siv.models.mymodel as mymodel
+    import siv.rng as srng
+    from tests.test_oracle_golden import fc_inputs
+    from tests.fc_truth import assert_grad_as_good_as_reference, fc_step0_fp64
+    g = load("g7_fc.npz")
+    cfgt, x, zz, steps = fc_inputs(g)
+    net = mymodel.SoftIntroVAE(*cfgt)
+    net.load_state_dict(sd_from(g, "sd0."))
+    net = net.to("cuda").train()
+    draws = O.Draws(seed=int(g["draw_seed"]))
+    with srng.use_rng(srng.ReplayRng(draws)):
+        fmu, flv, fz, fx = net.forward(x.cuda())
+        xd = net.decode(zz.cuda())
+    for a, k in ((fmu, "fwd.mu"), (flv, "fwd.logvar"), (fz, "fwd.z"), (fx[:, :, 40], "fwd.x_slice"),
+                 (xd[:, :, 40], "dec.x_slice")):
+        check(a, g[k], k)
+    ref1 = sd_from(g, "sd1.")
+    for k, v in net.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(ref1[k]), k
+        else:
+            check(v, ref1[k], k, floor=1e-6)
+    net.eval()
+    with torch.no_grad():
+        emu, elv = net.encode(x.cuda())
+        ex = net.decode(zz.cuda())
+    for a, k in ((emu, "eval.mu"), (elv, "eval.logvar"), (ex[:, :, 40], "eval.x_slice")):
+        check(a, g[k], k)
+    net.train()
+    hp = O.Hyper(beta_rec=float(g["hp.beta_rec"]), beta_neg=float(g["hp.beta_neg"]),
+                 beta_kl=float(g["hp.beta_kl"]), gamma_r=float(g["hp.gamma_r"]), scale=float(g["hp.scale"]))
+    (st, grads), = _run_steps(net, lambda s: steps[s], hp, draws, 1)
+    # E-step scalars at 1e-4; the D-step runs on the encoder AFTER its first Adam update, which is
+    # sign-like (+-lr per element) and so turns noise-level gradient differences into weight
+    # differences: its scalars are pinned at 1e-3
+    for mine, ref, rt in (("lossE", "lossE", 1e-4), ("kl_real", "kl_real", 1e-4), ("lossD", "lossD", 1e-3),
+                          ("fake_kl", "fake_kl", 1e-3), ("rec_kl", "rec_kl", 1e-3),
+                          ("loss_rec", "loss_rec_D", 1e-3)):
+        np.testing.assert_allclose(st[mine], float(g[f"s0.{ref}"]), rtol=rt, err_msg=mine)
+    for mine in ("exp_elbo_rec", "exp_elbo_fake"):
+        np.testing.assert_allclose(np.log(st[mine]), np.log(float(g[f"s0.{mine}"])), rtol=1e-4, err_msg=mine)
+    truth = fc_step0_fp64()
+    for k, gr in grads.items():
+        which = "gradE" if k.startswith("encoder.") else "gradD"
+        key = f"s0.{which}.{k}"
+        if key + ".none" in g.files:
+            assert float(gr.abs().max()) == 0.0, key
+        elif float(np.abs(truth[f"{which}.{k}"]).max()) > 1e-4:     # skips BN-cancelled conv biases
+            assert_grad_as_good_as_reference(gr.numpy(), g[key], truth[f"{which}.{k}"], key)
+
+
+FC_WIDE = (8, 16, 32, 32, 48)
+
+
+def test_fc_wide_forward_matches_oracle():
+    """8-16-32-32 channel FC-latent model (matrix-core conv kernels with 8/16/32-wide tiles, pooled
+    BN tails, fused upsample, both Linear layers) forward in training mode against the oracle."""
+    import siv.models.mymodel as mymodel
+    import siv.rng as srng
+    torch.manual_seed(11)
+    net = mymodel.SoftIntroVAE(*FC_WIDE)
+    gen = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for m in net.modules():
+            if type(m) == torch.nn.Conv3d:
+                torch.nn.init.kaiming_normal_(m.weight, nonlinearity="leaky_relu")
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.copy_(1 + 0.2 * torch.randn(m.weight.shape, generator=gen))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.rand(2, 1, 80, 96, 80, generator=gen)
+    cfg = O.FcCfg(*FC_WIDE)
+    mu_r, lv_r, z_r, x_r = O.forward(x, sd, cfg, O.Draws(seed=3), True)
+    net = net.to("cuda").train()
+    with srng.use_rng(srng.ReplayRng(O.Draws(seed=3))):
+        mu, lv, z, xr = net.forward(x.cuda())
+    check(mu, mu_r, "mu")
+    check(lv, lv_r, "logvar")
+    check(z, z_r, "z")
+    check(xr, x_r, "x_re", tol=2e-4)
+    for k, v in net.state_dict().items():
+        if k.endswith(("running_mean", "running_var")):
+            check(v, sd[k], k, floor=1e-6)
+
+
+def test_trainer_fc_runs_on_device(tmp_path):
+    """siv.utils.trainer_fc end to end on the GPU with the device generator: finite losses, the
+    reference's list lengths, log files and checkpoint names."""
+    import siv.models.mymodel as mymodel
+    import siv.utils.trainer_fc as trainer_fc
+    torch.manual_seed(1)
+    net = mymodel.SoftIntroVAE(4, 8, 8, 8, 16)
+    gen = torch.Generator().manual_seed(2)
+    loader = [(torch.rand(2, 1, 80, 96, 80, generator=gen), torch.zeros(2)) for _ in range(2)]
+    res = trainer_fc.train_soft_intro_vae(net, loader, loader[:1], 1, 2e-4, torch.device("cuda"),
+                                          str(tmp_path) + "/", 1.0, 1024.0, 0.75)
+    assert all(len(r) == 2 and np.isfinite(r).all() for r in res)
+    assert (tmp_path / "prams" / "S-IntroVAE_4184_epoch0.pth").exists()
+    assert (tmp_path / "loss.txt").exists() and (tmp_path / "kl_losses.txt").exists()
+    sd = torch.load(tmp_path / "prams" / "S-IntroVAE_4184_epoch0.pth", weights_only=True)
+    assert list(sd.keys()) == list(net.state_dict().keys())

@@ -328,3 +328,47 @@ def test_axpby(B):
     check(yd, 0.5 * x + 2.0 * y, "axpby")
     B.axpby(0.25, yd, 0.0, yd)                                   # in-place scaling
     check(yd, 0.25 * (0.5 * x + 2.0 * y), "scale")
+
+
+@pytest.mark.parametrize("b,k,o", [(2, 1200, 32), (8, 19200, 1200), (8, 600, 19200), (3, 37, 5), (11, 130, 64)])
+def test_linear_fwd_dgrad_wgrad(B, b, k, o):
+    """nn.Linear of the FC-latent model (models/mymodel.py:125,151) incl. the benchmark shapes
+    (B=8: 19200 -> 1200 and 600 -> 19200), a ragged shape and a batch above one register tile."""
+    gen = torch.Generator().manual_seed(b * 7 + k + o)
+    x, w, bias = rnd(gen, b, k), rnd(gen, o, k, scale=k ** -0.5), rnd(gen, o)
+    dy = rnd(gen, b, o)
+    y = B.linear_fwd(dev(x), dev(w), dev(bias))
+    check(y, F.linear(x.double(), w.double(), bias.double()).float(), "linear fwd")
+    check(B.linear_fwd(dev(x), dev(w), None), F.linear(x.double(), w.double()).float(), "linear fwd (no bias)")
+    check(B.linear_dgrad(dev(dy), dev(w)), (dy.double() @ w.double()).float(), "linear dgrad")
+    dw, db = B.linear_wgrad(dev(x), dev(dy), True)
+    check(dw, (dy.double().t() @ x.double()).float(), "linear wgrad")
+    check(db, dy.double().sum(0).float(), "linear bias grad")
+    # adjoint identities tie the three kernels together
+    a = float((y.double().cpu() - bias.double()) .mul(dy.double()).sum())
+    bb = float((x.double() * B.linear_dgrad(dev(dy), dev(w)).double().cpu()).sum())
+    assert abs(a - bb) <= 1e-5 * float(y.double().norm() * dy.double().norm())
+
+
+def test_linear_rejects_bad_arguments(B):
+    import siv._lib as L
+    x = torch.zeros(2, 8, device="cuda")
+    with pytest.raises(L.SivError):
+        L.check(B.lib.siv_linear_fwd(x.data_ptr(), None, None, x.data_ptr(), 2, 8, 4, None), "siv_linear_fwd")
+    with pytest.raises(L.SivError):
+        L.check(B.lib.siv_linear_fwd(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 0, 8, 4, None), "siv_linear_fwd")
+    with pytest.raises(L.SivError):      # workspace too small for the split-row partial sums
+        L.check(B.lib.siv_linear_dgrad(x.data_ptr(), x.data_ptr(), x.data_ptr(), 2, 8, 4, x.data_ptr(), 16, None),
+                "siv_linear_dgrad")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 5, 6, 5), (3, 7), (1, 4, 10, 12, 10)])
+def test_add_act(B, shape):
+    gen = torch.Generator().manual_seed(len(shape))
+    a, b, dout = rnd(gen, *shape), rnd(gen, *shape), rnd(gen, *shape)
+    out = B.add_act_fwd(dev(a), dev(b), 0.2)
+    ref = F.leaky_relu(a + b, 0.2)
+    check(out, ref, "add_act fwd")
+    d = B.add_act_bwd(dev(dout), dev(a), dev(b), 0.2)
+    s = a + b
+    check(d, dout * torch.where(s > 0, torch.ones_like(s), torch.full_like(s, 0.2)), "add_act bwd", max_outliers=2)

@@ -141,3 +141,65 @@ def test_g6_vae():
         ref_sd = sd_from(g, f"s{step}.sd.")
         for k in ref_sd:
             close(sd[k], ref_sd[k], rtol=1e-5, atol=5e-6, what=f"s{step}.sd.{k}")
+
+
+def fc_inputs(g):
+    """The inputs tools/make_goldens.py::g7_fc drew, regenerated from the stored seed."""
+    cfg = tuple(int(v) for v in g["cfg"])
+    B = int(g["batch"])
+    gen = torch.Generator().manual_seed(int(g["data_seed"]))
+    x = torch.rand(B, 1, 80, 96, 80, generator=gen)
+    zz = torch.randn(B, cfg[4], generator=gen)
+    steps = [(torch.rand(B, 1, 80, 96, 80, generator=gen), torch.randn(B, cfg[4], generator=gen))
+             for _ in range(2)]
+    return cfg, x, zz, steps
+
+
+def test_g7_fc_model_and_step():
+    """models/mymodel.py (FC-latent) forward in train and eval mode, then two E+D iterations."""
+    g = load("g7_fc.npz")
+    cfgt, x, zz, steps = fc_inputs(g)
+    cfg = O.FcCfg(*cfgt)
+    sd = sd_from(g, "sd0.")
+    draws = O.Draws(seed=int(g["draw_seed"]))
+    fmu, flv, fz, fx = O.forward(x, sd, cfg, draws, True)
+    xd = O.decode(zz, sd, cfg, draws, True)
+    for a, k in ((fmu, "fwd.mu"), (flv, "fwd.logvar"), (fz, "fwd.z"), (fx[:, :, 40], "fwd.x_slice"),
+                 (xd[:, :, 40], "dec.x_slice")):
+        close(a, g[k], rtol=1e-4, atol=1e-5, what=k)
+    close(fx.double().sum(), g["fwd.x_sum"], rtol=1e-5)
+    close(xd.double().sum(), g["dec.x_sum"], rtol=1e-5)
+    sd1 = sd_from(g, "sd1.")
+    for k in sd1:
+        close(sd[k], sd1[k], what=k)
+    emu, elv = O.encode(x, sd, cfg, None, False)
+    ex = O.decode(zz, sd, cfg, None, False)
+    for a, k in ((emu, "eval.mu"), (elv, "eval.logvar"), (ex[:, :, 40], "eval.x_slice")):
+        close(a, g[k], rtol=1e-4, atol=1e-5, what=k)
+    hp = O.Hyper(beta_rec=float(g["hp.beta_rec"]), beta_neg=float(g["hp.beta_neg"]),
+                 beta_kl=float(g["hp.beta_kl"]), gamma_r=float(g["hp.gamma_r"]), scale=float(g["hp.scale"]))
+    ae, ad = {}, {}
+    for step, (real, noise) in enumerate(steps):
+        r = O.soft_intro_step(sd, cfg, real, noise, draws, hp, ae, ad)
+        for k in ("lossE", "lossD", "loss_rec_E", "loss_rec_D", "kl_real", "rec_kl", "fake_kl",
+                  "fake_kl_e", "rec_kl_e"):
+            close(r[k], g[f"s{step}.{k}"], rtol=2e-5, what=f"s{step}.{k}")
+        for k in ("exp_elbo_fake", "exp_elbo_rec"):
+            close(r[k], g[f"s{step}.{k}"], rtol=1e-3, atol=1e-30, what=k)
+        for which in ("gradE", "gradD"):
+            for pk, gr in r[which].items():
+                key = f"s{step}.{which}.{pk}"
+                if gr is None:
+                    assert key + ".none" in g.files, key      # encoder.block8.* is never called
+                else:
+                    ref = g[key]
+                    close(gr, ref, rtol=1e-4, atol=2e-5 * float(np.abs(ref).max()) + 3e-7, what=key)
+        ref_sd = sd_from(g, f"s{step}.sd.")
+        for k in ref_sd:
+            # every conv bias here is cancelled by the BatchNorm that follows: its gradient is
+            # rounding noise that Adam turns into a +-lr move
+            gk = [f"s{step}.{w}.{k}" for w in ("gradE", "gradD")]
+            noise_g = any(q in g.files and float(np.abs(g[q]).max()) < 1e-5 for q in gk)
+            close(sd[k], ref_sd[k], rtol=1e-5,
+                  atol=(2 * (step + 1) * hp.lr if noise_g else 2e-6), what=f"s{step}.sd.{k}")
+    assert draws.i == int(g["n_draws"])

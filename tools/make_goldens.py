@@ -415,7 +415,132 @@ def g8_train():
     print("g8_train", {k: v for k, v in zip(("tE", "tD", "vE", "vD"), res)}, "draws", draws.i)
 
 
-ALL = {"g2": g2_blocks, "g3": g3_model, "g4": g4_step, "g5": g5_losses, "g6": g6_vae, "g8": g8_train}
+# ---------------------------------------------------------------- G7 FC-latent model
+FC_CFG = (2, 4, 4, 8, 16)      # first, second, third, forth, z  (input is fixed at 80x96x80)
+FC_DIMS = (80, 96, 80)
+
+
+def build_fc(seed=83):
+    import models.mymodel as MM
+    torch.manual_seed(seed)
+    net = MM.SoftIntroVAE(*FC_CFG)
+    torch.manual_seed(78)
+    he_init(net)
+    randomize_affine(net, torch.Generator().manual_seed(7))
+    return net
+
+
+def _store_step(out, step, r):
+    for k, v in r.items():
+        if k in ("gradE", "gradD"):
+            pre = "encoder." if k == "gradE" else "decoder."
+            for pk, g in v.items():
+                if g is not None:
+                    out[f"s{step}.{k}.{pre}{pk}"] = g.numpy()
+                else:
+                    out[f"s{step}.{k}.{pre}{pk}.none"] = np.array(1)
+        else:
+            out[f"s{step}.{k}"] = np.asarray(v)
+
+
+def g7_fc():
+    """models/mymodel.py SoftIntroVAE: train/eval forward, then two E+D iterations with the
+    call sequence of utils/trainer_fc.py:221-299.  Inputs are regenerated from the stored
+    generator seed (two 80x96x80 batches would dominate the fixture otherwise)."""
+    _stub_missing_modules()
+    import utils.trainer_fc as TF
+    net = build_fc()
+    B = 2
+    gen = torch.Generator().manual_seed(107)
+    x = torch.rand(B, 1, *FC_DIMS, generator=gen)
+    zz = torch.randn(B, FC_CFG[4], generator=gen)
+    out = sd_np(net.state_dict(), "sd0.")
+    out["cfg"], out["data_seed"], out["batch"] = np.array(FC_CFG), np.array(107), np.array(B)
+    net.train()
+    draws = Draws(seed=71)
+    with patched_random(draws):
+        fmu, flv, fz, fx = net.forward(x)
+        xd = net.decode(zz)
+    out.update({"fwd.mu": fmu.detach().numpy(), "fwd.logvar": flv.detach().numpy(), "fwd.z": fz.detach().numpy(),
+                "fwd.x_sum": np.array(fx.detach().double().sum().item()),
+                "fwd.x_slice": fx.detach()[:, :, 40].numpy(),
+                "dec.x_sum": np.array(xd.detach().double().sum().item()),
+                "dec.x_slice": xd.detach()[:, :, 40].numpy()})
+    out.update(sd_np(net.state_dict(), "sd1."))
+    net.eval()
+    with torch.no_grad(), patched_random(draws):
+        emu, elv = net.encode(x)
+        ex = net.decode(zz)
+    out.update({"eval.mu": emu.numpy(), "eval.logvar": elv.numpy(),
+                "eval.x_sum": np.array(ex.double().sum().item()), "eval.x_slice": ex[:, :, 40].numpy()})
+    net.train()
+    hp = dict(scale=8.0 / np.prod(FC_DIMS), beta_rec=1.0, beta_neg=1024.0, beta_kl=0.75, gamma_r=1e-8)
+    opt_e = torch.optim.Adam(net.encoder.parameters(), lr=2e-4)
+    opt_d = torch.optim.Adam(net.decoder.parameters(), lr=2e-4)
+    with patched_random(draws):
+        for step in range(2):
+            real = torch.rand(B, 1, *FC_DIMS, generator=gen)
+            noise = torch.randn(B, FC_CFG[4], generator=gen)
+            _store_step(out, step, reference_step(net, TF, real, noise, opt_e, opt_d, hp))
+            out.update(sd_np(net.state_dict(), f"s{step}.sd."))
+    out["draw_seed"] = np.array(71)
+    out["n_draws"] = np.array(draws.i)
+    for k, v in hp.items():
+        out["hp." + k] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, "g7_fc.npz"), **out)
+    print("g7_fc", len(out), "draws", draws.i)
+
+
+def g9_train_fc():
+    """The REAL reference utils/trainer_fc.py train_soft_intro_vae on models/mymodel.py:
+    2 epochs x 2 train batches + 1 val batch, B=8 (save_image indexes 8 images)."""
+    _stub_missing_modules()
+    import utils.trainer_fc as TF
+    import models.mymodel as MM
+    torch.manual_seed(84)
+    net = MM.SoftIntroVAE(*FC_CFG)
+    gen = torch.Generator().manual_seed(109)
+    train = [(torch.rand(8, 1, *FC_DIMS, generator=gen), torch.zeros(8)) for _ in range(2)]
+    val = [(torch.rand(8, 1, *FC_DIMS, generator=gen), torch.zeros(8))]
+    out = {"cfg": np.array(FC_CFG), "data_seed": np.array(109)}
+    draws = Draws(seed=91)
+    orig_randn = torch.randn
+    torch.randn = lambda *a, size=None, **k: draws.eps(size if size is not None else a[0] if isinstance(a[0], (tuple, list, torch.Size)) else a)
+    orig_apply = nn.Module.apply
+    captured = {}
+
+    def apply_and_capture(self, fn):
+        r = orig_apply(self, fn)
+        if self is net and "sd" not in captured and getattr(fn, "__name__", "") == "init_weights_he":
+            captured["sd"] = sd_np(self.state_dict(), "sd0.")
+        return r
+
+    nn.Module.apply = apply_and_capture
+    with tempfile.TemporaryDirectory() as d:
+        for sub in ("imgs", "fakeimgs", "val_imgs", "prams"):
+            os.makedirs(os.path.join(d, sub))
+        try:
+            with patched_random(draws):
+                res = TF.train_soft_intro_vae(net, ListLoader(train), ListLoader(val), 2, 2e-4,
+                                              torch.device("cpu"), d + "/", 1.0, 1024.0, 0.75)
+        finally:
+            torch.randn = orig_randn
+            nn.Module.apply = orig_apply
+        for name in ("loss.txt", "kl_losses.txt"):
+            with open(os.path.join(d, name)) as f:
+                out["txt." + name] = np.array(f.read())
+        out["files"] = np.array(sorted(os.listdir(os.path.join(d, "prams"))))
+    out.update(captured["sd"])
+    for name, lst in zip(("train_lossE", "train_lossD", "val_lossE", "val_lossD"), res):
+        out["ret." + name] = np.array(lst, dtype=np.float64)
+    out.update(sd_np(net.state_dict(), "sd_final."))
+    out["draw_seed"] = np.array(91)
+    out["n_draws"] = np.array(draws.i)
+    np.savez_compressed(os.path.join(OUT, "g9_train_fc.npz"), **out)
+    print("g9_train_fc", {k: v for k, v in zip(("tE", "tD", "vE", "vD"), res)}, "draws", draws.i)
+
+
+ALL = {"g7": g7_fc, "g9": g9_train_fc, "g2": g2_blocks, "g3": g3_model, "g4": g4_step, "g5": g5_losses, "g6": g6_vae, "g8": g8_train}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
