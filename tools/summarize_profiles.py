@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 output of tools/profile_round.sh (gpurun_out/prof_rNN/) into the files
+kept under profiles/: the kernel-stats CSV, a markdown summary of the dominant kernel's trace
+and PMC passes, and dominant_kernel_traffic.json (read by bench.py)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+SRC = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}")
+DST = os.path.join(ROOT, "profiles")
+DOM = "k3_fwd_mfma<4, 8, 8, 4, 1, 64, 1>"
+DOM_GRID = "4915200"          # 8 volumes x 80x96x80 / 256-voxel bricks x 256 threads
+ALGO_BYTES = 2 * 8 * 80 * 96 * 80 * 64 * 4 + 27 * 64 * 64 * 4     # read x + write y + weights
+ALGO_FLOP = 2.0 * 27 * 64 * 64 * 80 * 96 * 80 * 8
+
+
+def one(pattern):
+    return glob.glob(os.path.join(SRC, pattern))[0]
+
+
+def counters(d):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(one(f"{d}/vm/*_counter_collection.csv"))):
+        if DOM in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+
+
+def main():
+    bench = json.loads(open(os.path.join(SRC, "bench_default.json")).read().strip().splitlines()[-1])
+    vps = bench["value"]
+    shutil.copy(one("trace/vm/*_kernel_stats.csv"), os.path.join(DST, f"{TAG}_bench_kernel_stats_{vps:.1f}vps.csv"))
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            for r in csv.DictReader(open(one("trace/vm/*_kernel_trace.csv")))
+            if DOM in r["Kernel_Name"] and r["Grid_Size_X"] == DOM_GRID]
+    avg_ms = sum(durs) / len(durs)
+    fetch, write, sq = counters("pmc_fetch"), counters("pmc_write"), counters("pmc_sq")
+    fetch_b, write_b = fetch["FETCH_SIZE"] * 1024, write["WRITE_SIZE"] * 1024
+    traffic = 2 * fetch_b + write_b            # gfx950: FETCH_SIZE counts 128-B requests as 64 B
+    simd_cycles = sq["GRBM_GUI_ACTIVE"] / 8 * 1024       # per-XCD active cycles x 256 CUs x 4 SIMDs
+    with open(os.path.join(DST, "dominant_kernel_traffic.json"), "w") as f:
+        json.dump({"kernel": DOM, "workload": "3x3x3 conv 64->64 @80x96x80, batch 8, forward",
+                   "hbm_bytes_per_launch": int(traffic), "fetch_size_bytes_raw": int(fetch_b),
+                   "write_size_bytes": int(write_b), "algorithmic_bytes_per_launch": ALGO_BYTES,
+                   "note": "traffic = 2*FETCH_SIZE + WRITE_SIZE (KB -> bytes); FETCH_SIZE doubled as "
+                           "prescribed for gfx950; separate --pmc passes (tools/profile_round.sh)"}, f, indent=1)
+    with open(os.path.join(DST, f"{TAG}_pmc_conv.md"), "w") as f:
+        f.write(f"""# {TAG}: dominant kernel `{DOM}` (3x3x3 conv 64->64 @80x96x80, batch 8, fp32)
+
+Produced by `tools/profile_round.sh` on one MI355X, summarised by `tools/summarize_profiles.py`.
+
+## bench.py (default flags) on the same box
+`{json.dumps({k: bench[k] for k in ("value", "unit", "ms_per_step", "roofline", "cpu_baseline")})}`
+
+## rocprofv3 --kernel-trace --stats of `bench.py --steps 3 --warmup 1`
+* launches of this kernel at the dominant shape (grid {DOM_GRID}): {len(durs)}, average **{avg_ms:.3f} ms**
+  (bench.py's live HIP-event figure: {bench["roofline"]["avg_launch_ms"]} ms) = {ALGO_FLOP / avg_ms / 1e9:.1f} TFLOP/s
+* full per-kernel table: `{TAG}_bench_kernel_stats_{vps:.1f}vps.csv`
+
+## PMC passes (tools/bench_conv.py --shapes v0_64_64 --ops fwd, one counter group per run)
+| counter | per launch |
+|---|---|
+| FETCH_SIZE | {fetch["FETCH_SIZE"]:.0f} KB = {fetch_b / 1e9:.3f} GB raw, x2 (gfx950 correction) = {2 * fetch_b / 1e9:.3f} GB |
+| WRITE_SIZE | {write["WRITE_SIZE"]:.0f} KB = {write_b / 1e9:.3f} GB (= the output tensor exactly) |
+| HBM traffic (2*FETCH + WRITE) | **{traffic / 1e9:.2f} GB** vs algorithmic {ALGO_BYTES / 1e9:.2f} GB |
+| SQ_VALU_MFMA_BUSY_CYCLES | {sq["SQ_VALU_MFMA_BUSY_CYCLES"]:.4g} |
+| GRBM_GUI_ACTIVE (sum of 8 XCDs) | {sq["GRBM_GUI_ACTIVE"]:.4g} -> {sq["GRBM_GUI_ACTIVE"] / 8:.4g} cycles per launch |
+| MFMA pipe busy | **{100 * sq["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles:.1f} %** of SIMD-cycles |
+| SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY / SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY | {sq["SQ_WAVE_CYCLES"]:.4g} / {sq["SQ_WAIT_INST_ANY"]:.4g} / {sq["SQ_WAIT_ANY"]:.4g} / {sq["SQ_ACTIVE_INST_ANY"]:.4g} |
+
+Reading: the kernel is matrix-pipe bound (MFMA busy ~ achieved/peak).  The fetch side re-reads the
+6x10x10-voxel halo of every 4x8x8 brick (2.34x the input) -- those re-reads are served by L2 / the
+Infinity Cache (the counter sits on the L2's fabric side and includes Infinity-Cache hits) and, at
+{traffic / 1e9 / (avg_ms / 1e3) / 1e3:.2f} TB/s, are far from the HBM roof, so they do not bound the kernel.
+""")
+    print("wrote profiles for", TAG, "avg_ms", avg_ms, "traffic GB", traffic / 1e9)
+
+
+if __name__ == "__main__":
+    main()
