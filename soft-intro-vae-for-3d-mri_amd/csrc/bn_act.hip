@@ -303,6 +303,290 @@ __global__ __launch_bounds__(256) void act_dropout_bwd_k(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// float4 path.  Requires C % 4 == 0 and (C/4) a divisor of 256 (C = 4 .. 1024, power of two):
+// a thread of a 256-thread block then owns the same four channels in every iteration of a
+// grid-stride loop over channel quads, so per-channel coefficients live in registers and
+// no index arithmetic beyond an add is needed per 16-byte access.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4(const float* __restrict__ p, long q) {
+    return reinterpret_cast<const float4*>(p)[q];
+}
+__device__ __forceinline__ void st4(float* __restrict__ p, long q, float4 v) {
+    reinterpret_cast<float4*>(p)[q] = v;
+}
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 leaky4(float4 z, float s) {
+    return make_float4(leaky(z.x, s), leaky(z.y, s), leaky(z.z, s), leaky(z.w, s));
+}
+__device__ __forceinline__ float4 leaky_grad4(float4 z, float s) {
+    return make_float4(leaky_grad(z.x, s), leaky_grad(z.y, s), leaky_grad(z.z, s), leaky_grad(z.w, s));
+}
+__device__ __forceinline__ float4 keep4(const uint8_t* __restrict__ keep, long q, float4 v, float dscale) {
+    const uchar4 k = reinterpret_cast<const uchar4*>(keep)[q];
+    return make_float4(k.x ? v.x * dscale : 0.f, k.y ? v.y * dscale : 0.f, k.z ? v.z * dscale : 0.f,
+                       k.w ? v.w * dscale : 0.f);
+}
+
+// per-thread coefficients of its four channels
+struct Coef {
+    float4 a, b, mean, invstd;
+};
+__device__ __forceinline__ Coef load_coef(const float* __restrict__ mean, const float* __restrict__ var,
+                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          float eps, int c4) {
+    Coef k;
+    const float4 v = ld4(var, c4), g = ld4(gamma, c4), be = ld4(beta, c4);
+    k.mean = ld4(mean, c4);
+    k.invstd = make_float4(1.0f / sqrtf(v.x + eps), 1.0f / sqrtf(v.y + eps), 1.0f / sqrtf(v.z + eps),
+                           1.0f / sqrtf(v.w + eps));
+    // same association as the scalar kernels: a = gamma / sqrt(var + eps), b = beta - mean * a
+    k.a = make_float4(g.x / sqrtf(v.x + eps), g.y / sqrtf(v.y + eps), g.z / sqrtf(v.z + eps),
+                      g.w / sqrtf(v.w + eps));
+    k.b = make_float4(be.x - k.mean.x * k.a.x, be.y - k.mean.y * k.a.y, be.z - k.mean.z * k.a.z,
+                      be.w - k.mean.w * k.a.w);
+    return k;
+}
+
+// Sum the per-thread float4 pairs of the threads that own the same channel quad and write
+// the block's partial [2][C] row.  sh: 2 * 256 float4.
+__device__ __forceinline__ void block_reduce_quads(float4 s1, float4 s2, int C4, int C,
+                                                   float* __restrict__ part, float4* sh) {
+    sh[threadIdx.x] = s1;
+    sh[256 + threadIdx.x] = s2;
+    __syncthreads();
+    if ((int)threadIdx.x < C4) {
+        float4 a1 = f4(0.f), a2 = f4(0.f);
+        for (int t = threadIdx.x; t < 256; t += C4) {
+            a1 = a1 + sh[t];
+            a2 = a2 + sh[256 + t];
+        }
+        st4(part + ((long)blockIdx.x * 2 + 0) * C, threadIdx.x, a1);
+        st4(part + ((long)blockIdx.x * 2 + 1) * C, threadIdx.x, a2);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_partial_v(const float* __restrict__ y, long Q, int C,
+                                                          float* __restrict__ part) {
+    __shared__ float4 sh[512];
+    const int C4 = C >> 2;
+    const float4 shift = ld4(y, threadIdx.x % C4);
+    float4 s1 = f4(0.f), s2 = f4(0.f);
+    const long T = (long)gridDim.x * 256;
+    long q = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; q + 3 * T < Q; q += 4 * T) {
+        const float4 v0 = ld4(y, q), v1 = ld4(y, q + T), v2 = ld4(y, q + 2 * T), v3 = ld4(y, q + 3 * T);
+        const float4 d0 = v0 - shift, d1 = v1 - shift, d2 = v2 - shift, d3 = v3 - shift;
+        s1 = s1 + ((d0 + d1) + (d2 + d3));
+        s2 = fma4(d0, d0, s2);
+        s2 = fma4(d1, d1, s2);
+        s2 = fma4(d2, d2, s2);
+        s2 = fma4(d3, d3, s2);
+    }
+    for (; q < Q; q += T) {
+        const float4 d = ld4(y, q) - shift;
+        s1 = s1 + d;
+        s2 = fma4(d, d, s2);
+    }
+    block_reduce_quads(s1, s2, C4, C, part, sh);
+}
+
+// decode an output-space quad index of the pooled tensor into the quad index of its first
+// child in the full-resolution tensor; C4 is a power of two
+struct PoolGeom {
+    int Do, Ho, Wo, H, W, C4, log2C4;
+};
+__device__ __forceinline__ long pool_child0(long oq, const PoolGeom& g, long* strideW, long* strideH,
+                                            long* strideD) {
+    const unsigned vox = (unsigned)(oq >> g.log2C4);
+    const int cq = (int)(oq & (g.C4 - 1));
+    const unsigned ww = vox % g.Wo, t1 = vox / g.Wo;
+    const unsigned hh = t1 % g.Ho, t2 = t1 / g.Ho;
+    const unsigned dd = t2 % g.Do, n = t2 / g.Do;
+    *strideW = g.C4;
+    *strideH = (long)g.W * g.C4;
+    *strideD = (long)g.H * g.W * g.C4;
+    return ((((long)n * (2 * g.Do) + 2 * dd) * g.H + 2 * hh) * g.W + 2 * ww) * g.C4 + cq;
+}
+
+template <int POOL>
+__global__ __launch_bounds__(256) void bn_act_fwd_v(const float* __restrict__ y,
+                                                    const float* __restrict__ mean,
+                                                    const float* __restrict__ var,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta,
+                                                    const float* __restrict__ res,
+                                                    const uint8_t* __restrict__ keep, float p,
+                                                    float slope, float eps, float* __restrict__ out,
+                                                    long OQ, PoolGeom g) {
+    const Coef k = load_coef(mean, var, gamma, beta, eps, threadIdx.x % g.C4);
+    const float dscale = 1.0f / (1.0f - p);
+    const long T = (long)gridDim.x * 256;
+    long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (POOL == 1) {
+        for (; q + T < OQ; q += 2 * T) {
+            const float4 y0 = ld4(y, q), y1 = ld4(y, q + T);
+            float4 z0 = fma4(y0, k.a, k.b), z1 = fma4(y1, k.a, k.b);
+            if (res) {
+                z0 = z0 + ld4(res, q);
+                z1 = z1 + ld4(res, q + T);
+            }
+            float4 o0 = leaky4(z0, slope), o1 = leaky4(z1, slope);
+            if (keep) {
+                o0 = keep4(keep, q, o0, dscale);
+                o1 = keep4(keep, q + T, o1, dscale);
+            }
+            st4(out, q, o0);
+            st4(out, q + T, o1);
+        }
+        for (; q < OQ; q += T) {
+            float4 z = fma4(ld4(y, q), k.a, k.b);
+            if (res) z = z + ld4(res, q);
+            float4 o = leaky4(z, slope);
+            if (keep) o = keep4(keep, q, o, dscale);
+            st4(out, q, o);
+        }
+    } else {
+        for (; q < OQ; q += T) {
+            long sw, shh, sd;
+            const long j0 = pool_child0(q, g, &sw, &shh, &sd);
+            float4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = ld4(y, j0 + (e >> 2) * sd + ((e >> 1) & 1) * shh + (e & 1) * sw);
+            float4 acc = f4(0.f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float4 z = fma4(v[e], k.a, k.b);
+                if (res) z = z + ld4(res, j0 + (e >> 2) * sd + ((e >> 1) & 1) * shh + (e & 1) * sw);
+                acc = acc + leaky4(z, slope);
+            }
+            float4 o = acc * f4(0.125f);
+            if (keep) o = keep4(keep, q, o, dscale);
+            st4(out, q, o);
+        }
+    }
+}
+
+// One backward element quad: dz and xhat for input quad j with output-space gradient g.
+__device__ __forceinline__ float4 bwd_dz(float4 g, float4 yv, const float* __restrict__ res, long j,
+                                         const Coef& k, float slope, float4* xh) {
+    float4 z = fma4(yv, k.a, k.b);
+    if (res) z = z + ld4(res, j);
+    *xh = (yv - k.mean) * k.invstd;
+    return g * leaky_grad4(z, slope);
+}
+
+// APPLY = 0: per-block partial sums of dz and dz*xhat.  APPLY = 1: dy (and dres) from the sums.
+template <int POOL, int APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_v(const float* __restrict__ dout,
+                                                const float* __restrict__ y,
+                                                const float* __restrict__ mean,
+                                                const float* __restrict__ var,
+                                                const float* __restrict__ gamma,
+                                                const float* __restrict__ beta,
+                                                const float* __restrict__ res,
+                                                const uint8_t* __restrict__ keep, float p, float slope,
+                                                float eps, const float* __restrict__ sums, float invM,
+                                                long OQ, PoolGeom g, int C, float* __restrict__ part,
+                                                float* __restrict__ dy, float* __restrict__ dres) {
+    __shared__ float4 sh[APPLY ? 1 : 512];
+    const int c4 = threadIdx.x % g.C4;
+    const Coef k = load_coef(mean, var, gamma, beta, eps, c4);
+    float4 k1 = f4(0.f), k2 = f4(0.f);
+    if (APPLY) {
+        k1 = ld4(sums, c4) * f4(invM);
+        k2 = ld4(sums + C, c4) * f4(invM);
+    }
+    const float dscale = 1.0f / (1.0f - p);
+    float4 s1 = f4(0.f), s2 = f4(0.f);
+    const long T = (long)gridDim.x * 256;
+    long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (POOL == 1) {
+        for (; q + T < OQ; q += 2 * T) {
+            float4 g0 = ld4(dout, q), g1 = ld4(dout, q + T);
+            const float4 y0 = ld4(y, q), y1 = ld4(y, q + T);
+            if (keep) {
+                g0 = keep4(keep, q, g0, dscale);
+                g1 = keep4(keep, q + T, g1, dscale);
+            }
+            float4 x0, x1;
+            const float4 d0 = bwd_dz(g0, y0, res, q, k, slope, &x0);
+            const float4 d1 = bwd_dz(g1, y1, res, q + T, k, slope, &x1);
+            if (APPLY) {
+                st4(dy, q, k.a * (d0 - k1 - x0 * k2));
+                st4(dy, q + T, k.a * (d1 - k1 - x1 * k2));
+                if (dres) {
+                    st4(dres, q, d0);
+                    st4(dres, q + T, d1);
+                }
+            } else {
+                s1 = s1 + (d0 + d1);
+                s2 = fma4(d0, x0, s2);
+                s2 = fma4(d1, x1, s2);
+            }
+        }
+        for (; q < OQ; q += T) {
+            float4 g0 = ld4(dout, q);
+            if (keep) g0 = keep4(keep, q, g0, dscale);
+            float4 x0;
+            const float4 d0 = bwd_dz(g0, ld4(y, q), res, q, k, slope, &x0);
+            if (APPLY) {
+                st4(dy, q, k.a * (d0 - k1 - x0 * k2));
+                if (dres) st4(dres, q, d0);
+            } else {
+                s1 = s1 + d0;
+                s2 = fma4(d0, x0, s2);
+            }
+        }
+    } else {
+        for (; q < OQ; q += T) {
+            long sw, shh, sd;
+            const long j0 = pool_child0(q, g, &sw, &shh, &sd);
+            float4 go = ld4(dout, q);
+            if (keep) go = keep4(keep, q, go, dscale);
+            go = go * f4(0.125f);
+            float4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = ld4(y, j0 + (e >> 2) * sd + ((e >> 1) & 1) * shh + (e & 1) * sw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const long j = j0 + (e >> 2) * sd + ((e >> 1) & 1) * shh + (e & 1) * sw;
+                float4 xh;
+                const float4 d = bwd_dz(go, v[e], res, j, k, slope, &xh);
+                if (APPLY) {
+                    st4(dy, j, k.a * (d - k1 - xh * k2));
+                    if (dres) st4(dres, j, d);
+                } else {
+                    s1 = s1 + d;
+                    s2 = fma4(d, xh, s2);
+                }
+            }
+        }
+    }
+    if (!APPLY) block_reduce_quads(s1, s2, g.C4, C, part, sh);
+}
+
+static inline bool aligned16(const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; }
+// float4 path applicable?
+static inline bool vec_channels(int C) { return C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0; }
+static inline int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+static inline int vec_grid(long quads, int per_thread) {
+    long g = cdiv(quads, 256L * per_thread);
+    if (g > kMaxStatBlocks) g = kMaxStatBlocks;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
 static inline int stream_grid(long total) {
     long g = cdiv(total, 256);
     if (g > 256L * 16) g = 256L * 16;
@@ -327,10 +611,14 @@ extern "C" int siv_bn_stats(const float* y, long M, int C, float* mean, float* v
     SIV_CHECK_ARG(M > 0 && C > 0, "bn_stats: bad shape M=%ld C=%d", M, C);
     SIV_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr),
                   "bn_stats: running_mean and running_var must both be given or both be NULL");
-    const int nblk = stat_blocks(M);
+    const bool vec = vec_channels(C) && aligned16(y) && aligned16(ws);
+    const int nblk = vec ? vec_grid(M * (C / 4), 8) : stat_blocks(M);
     SIV_CHECK_WS((size_t)nblk * 2 * C * sizeof(float), ws_bytes, "bn_stats");
     hipStream_t s = (hipStream_t)stream;
-    bn_stats_partial<<<nblk, 256, 512 * sizeof(float), s>>>(y, M, C, (float*)ws);
+    if (vec)
+        bn_stats_partial_v<<<nblk, 256, 0, s>>>(y, M * (C / 4), C, (float*)ws);
+    else
+        bn_stats_partial<<<nblk, 256, 512 * sizeof(float), s>>>(y, M, C, (float*)ws);
     SIV_CHECK_LAUNCH("bn_stats(partial)");
     bn_stats_finalize<<<(C + 3) / 4, 256, 0, s>>>(y, (const float*)ws, nblk, M, C, mean, var,
                                                       running_mean, running_var,
@@ -351,6 +639,20 @@ extern "C" int siv_bn_act_fwd(const float* y, const float* mean, const float* va
     SIV_CHECK_ARG(p >= 0.f && p < 1.f, "bn_act_fwd: dropout p out of range");
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)N * (D / pool) * (H / pool) * (W / pool) * C;
+    if (vec_channels(C) && (long)N * D * H * W < (1L << 31) && aligned16(y) && aligned16(out) &&
+        aligned16(residual) && aligned16(mean) && aligned16(var) && aligned16(gamma) && aligned16(beta) &&
+        ((uintptr_t)keep & 3) == 0) {
+        const PoolGeom g = {D / pool, H / pool, W / pool, H, W, C / 4, ilog2(C / 4)};
+        const long OQ = total / 4;
+        if (pool == 1)
+            bn_act_fwd_v<1><<<vec_grid(OQ, 4), 256, 0, s>>>(y, mean, var, gamma, beta, residual, keep, p,
+                                                            slope, eps, out, OQ, g);
+        else
+            bn_act_fwd_v<2><<<vec_grid(OQ, 1), 256, 0, s>>>(y, mean, var, gamma, beta, residual, keep, p,
+                                                            slope, eps, out, OQ, g);
+        SIV_CHECK_LAUNCH("bn_act_fwd");
+        return SIV_OK;
+    }
     if (pool == 1)
         bn_act_fwd_k<1><<<stream_grid(total), 256, 0, s>>>(y, mean, var, gamma, beta, residual, keep, p,
                                                            slope, eps, out, N, D, H, W, C);
@@ -375,12 +677,39 @@ extern "C" int siv_bn_act_bwd(const float* dout, const float* y, const float* me
     SIV_CHECK_ARG(dresidual == nullptr || residual != nullptr,
                   "bn_act_bwd: dresidual requested without residual");
     const long M = (long)N * D * H * W;
-    const int nblk = stat_blocks(M);
+    const bool vec = vec_channels(C) && M < (1L << 31) && aligned16(dout) && aligned16(y) && aligned16(dy) &&
+                     aligned16(residual) && aligned16(dresidual) && aligned16(mean) && aligned16(var) &&
+                     aligned16(gamma) && aligned16(beta) && aligned16(ws) && ((uintptr_t)keep & 3) == 0;
+    const long OQ = (long)N * (D / pool) * (H / pool) * (W / pool) * (C / 4);   // loop extent of the float4 path
+    const int nblk = vec ? vec_grid(OQ, pool == 1 ? 8 : 2) : stat_blocks(M);
     const size_t part_bytes = align256((size_t)nblk * 2 * C * sizeof(float));
     SIV_CHECK_WS(part_bytes + (size_t)2 * C * sizeof(float), ws_bytes, "bn_act_bwd");
     float* part = (float*)ws;
     float* sums = (float*)((char*)ws + part_bytes);
     hipStream_t s = (hipStream_t)stream;
+    if (vec) {
+        const PoolGeom g = {D / pool, H / pool, W / pool, H, W, C / 4, ilog2(C / 4)};
+        const float invM = 1.0f / (float)M;
+        if (pool == 1)
+            bn_bwd_v<1, 0><<<nblk, 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual, keep, p, slope, eps,
+                                                nullptr, invM, OQ, g, C, part, nullptr, nullptr);
+        else
+            bn_bwd_v<2, 0><<<nblk, 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual, keep, p, slope, eps,
+                                                nullptr, invM, OQ, g, C, part, nullptr, nullptr);
+        SIV_CHECK_LAUNCH("bn_act_bwd(partial)");
+        bn_bwd_finalize<<<(C + 3) / 4, 256, 0, s>>>(part, nblk, C, sums, dgamma, dbeta, accumulate);
+        SIV_CHECK_LAUNCH("bn_act_bwd(finalize)");
+        if (pool == 1)
+            bn_bwd_v<1, 1><<<vec_grid(OQ, 4), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual, keep, p,
+                                                           slope, eps, sums, invM, OQ, g, C, nullptr, dy,
+                                                           dresidual);
+        else
+            bn_bwd_v<2, 1><<<vec_grid(OQ, 1), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual, keep, p,
+                                                           slope, eps, sums, invM, OQ, g, C, nullptr, dy,
+                                                           dresidual);
+        SIV_CHECK_LAUNCH("bn_act_bwd(apply)");
+        return SIV_OK;
+    }
     if (pool == 1)
         bn_bwd_partial<1><<<nblk, 256, 512 * sizeof(float), s>>>(dout, y, mean, var, gamma, beta,
                                                                  residual, keep, p, slope, eps, M, D,
