@@ -176,6 +176,99 @@ __global__ __launch_bounds__(256) void c_to_one_k(const float* __restrict__ a,
 }
 
 // ---------------------------------------------------------------------------------
+// c_to_one on the matrix pipe (C = 8*KG <= 64).  Stage 1 is a small GEMM per brick:
+//   p[u][tap] = sum_c a[u][c] * wk[tap][c],  u over the 600 halo voxels (19 tiles of 32 rows),
+//   27 taps padded to the 32 columns of v_mfma_f32_32x32x2_f32, K = C.
+// A rows come straight from global memory (lane (i,h) reads the 16-byte channel quad 4h of every
+// 8-channel group of voxel i: the k order is permuted identically for A and B), the weights sit
+// in registers, the p image goes to LDS and stage 2 gathers out[v] = b + sum_tap p[v+tap-1][tap].
+// The VALU kernel above spends its time re-reading the weights from LDS for every voxel.
+// ---------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int C1M_TILES = (TH_V + 31) / 32;   // 19
+
+template <int KG>
+__device__ __forceinline__ void c1m_load_tile(const float* __restrict__ a, int tile, int i, int h, int n,
+                                              int z0, int y0, int x0, int D, int H, int W, int C,
+                                              float4 (&av)[KG]) {
+    const int u = tile * 32 + i;
+    const int hx = u % TH_W, hy = (u / TH_W) % TH_H, hz = u / (TH_W * TH_H);
+    const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+    const bool ok = u < TH_V && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const float* src = a + ((((long)n * D + gz) * H + gy) * W + gx) * C + 4 * h;
+#pragma unroll
+    for (int g = 0; g < KG; ++g)
+        av[g] = ok ? *reinterpret_cast<const float4*>(src + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int KG>
+__global__ __launch_bounds__(256) void c_to_one_mfma_k(const float* __restrict__ a,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ out, int N, int D, int H,
+                                                       int W, int flip, int nbd, int nbh, int nbw) {
+    constexpr int C = 8 * KG;
+    __shared__ float pim[TH_V * C1_PP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    // B fragments: column i = tap (27 used), k slots = channels 8g + 4h + {0..3}
+    float4 bw[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < 27) {
+            const int c = 8 * g + 4 * h;
+            if (!flip) {   // w is [1][27][C]
+                v = *reinterpret_cast<const float4*>(w + i * C + c);
+            } else {       // w is [C][27][1], taps reversed
+                v = make_float4(w[(c + 0) * 27 + 26 - i], w[(c + 1) * 27 + 26 - i],
+                                w[(c + 2) * 27 + 26 - i], w[(c + 3) * 27 + 26 - i]);
+            }
+        }
+        bw[g] = v;
+    }
+    int n, z0, y0, x0;
+    brick_coords(blockIdx.x, nbd, nbh, nbw, n, z0, y0, x0);
+    float4 av[KG], nx[KG];
+    c1m_load_tile<KG>(a, wv, i, h, n, z0, y0, x0, D, H, W, C, av);
+    for (int tile = wv; tile < C1M_TILES; tile += 4) {
+        if (tile + 4 < C1M_TILES) c1m_load_tile<KG>(a, tile + 4, i, h, n, z0, y0, x0, D, H, W, C, nx);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].x, bw[g].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].y, bw[g].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].z, bw[g].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].w, bw[g].w, acc, 0, 0, 0);
+        }
+        if (i < 27) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int u = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (u < TH_V) pim[u * C1_PP + i] = acc[r];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < KG; ++g) av[g] = nx[g];
+    }
+    __syncthreads();
+    const int m = threadIdx.x;
+    const int dz = m >> 6, dy = (m >> 3) & 7, dx = m & 7;
+    const int gz = z0 + dz, gy = y0 + dy, gx = x0 + dx;
+    if (gz < D && gy < H && gx < W) {
+        float s = bias ? bias[0] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const int hv = ((dz + t / 9) * TH_H + dy + (t / 3) % 3) * TH_W + dx + t % 3;
+            s += pim[hv * C1_PP + t];
+        }
+        out[(((long)n * D + gz) * H + gy) * W + gx] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // thin_wg.  Thread = (voxel lane, channel quad) with 27 (+1 for the plain sum of g) float4
 // accumulators; every block walks a contiguous range of bricks, then the voxel lanes are
 // combined through LDS and one partial row per block is written: part[block][C][28].
@@ -292,6 +385,14 @@ int k3_thin_fwd_launch(const float* a, const float* w, const float* bias, float*
     }
     if (Ca == 1)
         one_to_c_k<<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, Cb, flip, nbd, nbh, nbw);
+    else if (Ca == 64)
+        c_to_one_mfma_k<8><<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nbd, nbh, nbw);
+    else if (Ca == 32)
+        c_to_one_mfma_k<4><<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nbd, nbh, nbw);
+    else if (Ca == 16)
+        c_to_one_mfma_k<2><<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nbd, nbh, nbw);
+    else if (Ca == 8)
+        c_to_one_mfma_k<1><<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nbd, nbh, nbw);
     else
         c_to_one_k<<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, Ca, flip, nbd, nbh, nbw);
     SIV_CHECK_LAUNCH("conv3d_k3(thin)");
