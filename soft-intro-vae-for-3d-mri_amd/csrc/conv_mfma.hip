@@ -14,7 +14,8 @@
 #include "siv_common.h"
 
 // SIV_EXP is a timing-only ablation mask used by tools/ubench (never set in the library build):
-// 1 = no weight-fragment loads, 2 = no LDS fragment reads, 4 = no halo staging.
+// 1 = no weight-fragment loads, 2 = no LDS fragment reads, 4 = no halo staging,
+// 8 = no output stores, 16 = no block barriers, 32 = no LDS halo writes, 128 = scalar epilogue.
 #ifndef SIV_EXP
 #define SIV_EXP 0
 #endif
@@ -45,7 +46,11 @@ struct FwdCfg {
     static constexpr int HV = HD * HH * HW;
     static constexpr int CKP = CK + 4;         // padded channel stride (keeps 16-B alignment)
     static constexpr int HAL_FLOATS = HV * CKP;
-    static constexpr size_t LDS_BYTES = (size_t)HAL_FLOATS * sizeof(float);
+    static constexpr int EPI_STRIDE = 40;      // row stride of the epilogue's transpose tile: the two
+                                               // lane halves (4 rows apart) land 32 banks apart
+    static constexpr int EPI_FLOATS = 32 * EPI_STRIDE;
+    static constexpr int LDS_FLOATS = HAL_FLOATS > 4 * EPI_FLOATS ? HAL_FLOATS : 4 * EPI_FLOATS;
+    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
     static_assert(M % 32 == 0 && MS % WM == 0 && NS % WN == 0 && WM * WN == 4, "bad tiling");
 };
 
@@ -120,14 +125,14 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
     };
     load_halo(0);
     for (int cc = 0; cc < nchunk; ++cc) {
-        __syncthreads();  // previous chunk's MFMAs are done with the halo
+        if (!(SIV_EXP & 16)) __syncthreads();  // previous chunk's MFMAs are done with the halo
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
             const int idx = tid + 256 * i;
-            if ((idx >> 1) < C::HV)
+            if ((idx >> 1) < C::HV && (!(SIV_EXP & 32) || hreg[i].x == 123.f))
                 *reinterpret_cast<float4*>(hal + (idx >> 1) * C::CKP + 4 * (idx & 1)) = hreg[i];
         }
-        __syncthreads();
+        if (!(SIV_EXP & 16)) __syncthreads();
         if (cc + 1 < nchunk) load_halo((cc + 1) * C::CK);
         const float* wc = wlane + (long)cc * 27 * C::SLICE;
         // A fragments are read one tap ahead of their MFMAs as well, so that neither the LDS
@@ -177,7 +182,40 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
         }
     }
 
-    // epilogue: lane holds column co, rows (r&3)+8*(r>>2)+4*lh of each sub-tile
+    // epilogue.  A lane holds one column (output channel) of 16 rows per accumulator; writing that
+    // directly costs 16 scattered 4-byte stores per accumulator.  Instead every wave transposes
+    // one 32x32 accumulator at a time through its own slice of the (now idle) halo LDS and
+    // writes whole 128-byte channel runs with 16-byte stores.
+    if ((Cout & 3) == 0 && !(SIV_EXP & 128)) {
+        float* tile = hal + wave * C::EPI_FLOATS;
+#pragma unroll
+        for (int a = 0; a < C::AM; ++a) {
+#pragma unroll
+            for (int bb = 0; bb < C::AN; ++bb) {
+                __syncthreads();   // halo reads (first pass) / previous tile's reads are done
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * C::EPI_STRIDE + li] = acc[a][bb][r];
+                __syncthreads();
+                const int cq = lane & 7;
+                const int co = co0 + (wn * C::AN + bb) * 32 + 4 * cq;
+                float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (bias && co < Cout) bq = *reinterpret_cast<const float4*>(bias + co);
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int row = ps * 8 + (lane >> 3);
+                    const int m = (wm * C::AM + a) * 32 + row;
+                    const int gz = z0 + m / (BH * BW), gy = y0 + (m / BW) % BH, gx = x0 + m % BW;
+                    float4 v = *reinterpret_cast<const float4*>(tile + row * C::EPI_STRIDE + 4 * cq);
+                    v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                    if (gz < D && gy < H && gx < W && co < Cout && (!(SIV_EXP & 8) || v.x == 123.f))
+                        *reinterpret_cast<float4*>(y + ((((long)n * D + gz) * H + gy) * W + gx) * Cout + co) = v;
+                }
+            }
+        }
+        return;
+    }
+    // any other channel count: lane holds column co, rows (r&3)+8*(r>>2)+4*lh of each sub-tile
 #pragma unroll
     for (int bb = 0; bb < C::AN; ++bb) {
         const int co = co0 + (wn * C::AN + bb) * 32 + li;
@@ -189,7 +227,7 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
             for (int r = 0; r < 16; ++r) {
                 const int m = (wm * C::AM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int gz = z0 + m / (BH * BW), gy = y0 + (m / BW) % BH, gx = x0 + m % BW;
-                if (gz < D && gy < H && gx < W)
+                if (gz < D && gy < H && gx < W && (!(SIV_EXP & 8) || acc[a][bb][r] == 123.f))
                     y[((((long)n * D + gz) * H + gy) * W + gx) * Cout + co] = acc[a][bb][r] + bv;
             }
         }
