@@ -320,24 +320,26 @@ int k3_fwd_mfma_launch(const float* x, const float* w, const float* bias, float*
 // ---------------------------------------------------------------------------------
 // wgrad
 // ---------------------------------------------------------------------------------
-// Block = (range of 2x4x8-voxel bricks) x (one kd plane of taps) x (64 co x 64 ci tile).
+// Block = (range of 2x4xBW-voxel bricks) x (one kd plane of taps) x (64 co x 64 ci tile).
 // Wave w owns co half (w&1), ci half (w>>1) and the 9 taps (kh,kw) of the plane.
-template <int UPS>
+// BW = 8, or 10 for volumes whose width is a multiple of 10 but not of 8 (20, 10: the two
+// deepest levels of an 80x96x80 input) -- voxels are the K dimension, so padding is pure waste.
+template <int UPS, int BW_>
 struct WgCfg {
-    static constexpr int BD = 2, BH = 4, BW = 8;
-    static constexpr int M = BD * BH * BW;       // 64 voxels = 32 k-steps
+    static constexpr int BD = 2, BH = 4, BW = BW_;
+    static constexpr int M = BD * BH * BW;       // 64 (80) voxels = 32 (40) k-steps
     static constexpr int HH = BH + 2, HW = BW + 2;
-    static constexpr int HV = BD * HH * HW;      // 120 halo voxels in one kd plane
+    static constexpr int HV = BD * HH * HW;      // 120 (144) halo voxels in one kd plane
     static constexpr int CP = 64;
     static constexpr size_t LDS_BYTES = (size_t)(M * CP + HV * CP) * sizeof(float);
 };
 
 // Global -> register stage of one brick (issued one brick ahead of its use), then register -> LDS.
-template <int UPS>
+template <int UPS, int BW_>
 struct WgStage {
-    using C = WgCfg<UPS>;
-    static constexpr int NDY = C::M * 16 / 256;                 // 4 float4 of dy per thread
-    static constexpr int NX = (C::HV * 16 + 255) / 256;         // 8 float4 of x per thread (last partial)
+    using C = WgCfg<UPS, BW_>;
+    static constexpr int NDY = C::M * 16 / 256;                 // 4 (5) float4 of dy per thread
+    static constexpr int NX = (C::HV * 16 + 255) / 256;         // 8 (9) float4 of x per thread (last partial)
     float4 dyr[NDY];
     float4 xr[NX];
 
@@ -356,7 +358,7 @@ struct WgStage {
         for (int i = 0; i < NDY; ++i) {
             const int idx = tid + 256 * i;
             const int m = idx >> 4, q = idx & 15;
-            const int gz = z0 + (m >> 5), gy = y0 + ((m >> 3) & 3), gx = x0 + (m & 7);
+            const int gz = z0 + m / (C::BH * C::BW), gy = y0 + (m / C::BW) % C::BH, gx = x0 + m % C::BW;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gz < D && gy < H && gx < W && co0 + 4 * q < Cout)
                 v = *reinterpret_cast<const float4*>(
@@ -393,13 +395,13 @@ struct WgStage {
     }
 };
 
-template <int UPS>
+template <int UPS, int BW_>
 __global__ __launch_bounds__(256, 2) void k3_wgrad_mfma(const float* __restrict__ x,
                                                         const float* __restrict__ dy,
                                                         float* __restrict__ part, int N, int D, int H,
                                                         int W, int Cin, int Cout, int nbd, int nbh,
                                                         int nbw, int bricks_per_block) {
-    using C = WgCfg<UPS>;
+    using C = WgCfg<UPS, BW_>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* dyl = lds;                 // [64 voxels][64 co]
     float* xl = lds + C::M * C::CP;   // [120 halo voxels][64 ci]
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void k3_wgrad_mfma(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    WgStage<UPS> st;
+    WgStage<UPS, BW_> st;
     if (b0 < b1) st.load(x, dy, b0, kd, co0, ci0, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
     for (long br = b0; br < b1; ++br) {
         __syncthreads();              // the previous brick's MFMAs are done with LDS
@@ -436,9 +438,10 @@ __global__ __launch_bounds__(256, 2) void k3_wgrad_mfma(const float* __restrict_
         const float* bp = xl + lh * C::CP + is * 32 + li;
         if (active)
 #pragma unroll 4
-        for (int kk = 0; kk < 32; ++kk) {
-            // voxels 2kk + lh: dx = 2*(kk&3) + lh, dy = (kk>>2)&3, dz = kk>>4
-            const int hbase = ((kk >> 4) * C::HH + ((kk >> 2) & 3)) * C::HW + 2 * (kk & 3);
+        for (int kk = 0; kk < C::M / 2; ++kk) {
+            // voxels 2kk + lh: dx = 2*(kk % (BW/2)) + lh, dy = (kk / (BW/2)) % BH, dz = kk / (BW/2*BH)
+            constexpr int HB = C::BW / 2;
+            const int hbase = ((kk / (HB * C::BH)) * C::HH + (kk / HB) % C::BH) * C::HW + 2 * (kk % HB);
             const float a = ap[2 * kk * C::CP];
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -479,7 +482,8 @@ bool k3_wgrad_mfma_supported(int Cin, int Cout) {
 int k3_wgrad_mfma_launch(const float* x, const float* dy, float* dw, int N, int D, int H, int W,
                          int Cin, int Cout, int ups, int accumulate, void* ws, size_t ws_bytes,
                          hipStream_t s) {
-    const int nbd = (D + 1) / 2, nbh = (H + 3) / 4, nbw = (W + 7) / 8;
+    const bool wide = (W % 10 == 0) && (W % 8 != 0);
+    const int nbd = (D + 1) / 2, nbh = (H + 3) / 4, nbw = wide ? W / 10 : (W + 7) / 8;
     const long nbricks = (long)N * nbd * nbh * nbw;
     const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
     // enough blocks to fill the chip twice over, bounded by the workspace
@@ -499,15 +503,15 @@ int k3_wgrad_mfma_launch(const float* x, const float* dy, float* dw, int N, int 
     const int bpb = (int)cdiv(nbricks, nsplit);
     nsplit = cdiv(nbricks, bpb);
     dim3 grid((unsigned)nsplit, 3, (unsigned)tiles);
+#define SIV_WG(U, BWW)                                                                              \
+    k3_wgrad_mfma<U, BWW><<<grid, 256, WgCfg<U, BWW>::LDS_BYTES, s>>>(x, dy, (float*)ws, N, D, H, W, Cin, \
+                                                                      Cout, nbd, nbh, nbw, bpb)
     if (ups == 1) {
-        auto kern = k3_wgrad_mfma<1>;
-        kern<<<grid, 256, WgCfg<1>::LDS_BYTES, s>>>(x, dy, (float*)ws, N, D, H, W, Cin, Cout, nbd, nbh,
-                                                    nbw, bpb);
+        if (wide) SIV_WG(1, 10); else SIV_WG(1, 8);
     } else {
-        auto kern = k3_wgrad_mfma<2>;
-        kern<<<grid, 256, WgCfg<2>::LDS_BYTES, s>>>(x, dy, (float*)ws, N, D, H, W, Cin, Cout, nbd, nbh,
-                                                    nbw, bpb);
+        if (wide) SIV_WG(2, 10); else SIV_WG(2, 8);
     }
+#undef SIV_WG
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(mfma)");
     long g = cdiv(wsize, 256);
     if (g > 4096) g = 4096;
