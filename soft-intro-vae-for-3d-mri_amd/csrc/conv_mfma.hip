@@ -37,7 +37,9 @@ template <int BD, int BH, int BW, int WM, int WN, int NT, int UPS>
 struct FwdCfg {
     static constexpr int CK = 8;               // input channels per chunk
     static constexpr int M = BD * BH * BW;
-    static constexpr int MS = M / 32;          // 32-row sub-tiles in the brick
+    static constexpr int MS = (M + 31) / 32;   // 32-row sub-tiles in the brick (rows >= M are padding)
+    static constexpr int NW = WM * WN;         // waves per block
+    static constexpr int NTHR = 64 * NW;
     static constexpr int NS = NT / 32;         // NT (32 or 64) output channels per block
     static constexpr int SLICE = NT * 8;       // floats of one packed (chunk, tap) weight slice
     static constexpr int AM = MS / WM;         // accumulators per wave along M
@@ -49,13 +51,13 @@ struct FwdCfg {
     static constexpr int EPI_STRIDE = 40;      // row stride of the epilogue's transpose tile: the two
                                                // lane halves (4 rows apart) land 32 banks apart
     static constexpr int EPI_FLOATS = 32 * EPI_STRIDE;
-    static constexpr int LDS_FLOATS = HAL_FLOATS > 4 * EPI_FLOATS ? HAL_FLOATS : 4 * EPI_FLOATS;
+    static constexpr int LDS_FLOATS = HAL_FLOATS > NW * EPI_FLOATS ? HAL_FLOATS : NW * EPI_FLOATS;
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
-    static_assert(M % 32 == 0 && MS % WM == 0 && NS % WN == 0 && WM * WN == 4, "bad tiling");
+    static_assert(MS % WM == 0 && NS % WN == 0, "bad tiling");
 };
 
 template <int BD, int BH, int BW, int WM, int WN, int NT, int UPS>
-__global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
+__global__ __launch_bounds__(64 * WM * WN) void k3_fwd_mfma(const float* __restrict__ x,
                                                    const float* __restrict__ wp,
                                                    const float* __restrict__ bias,
                                                    float* __restrict__ y, int N, int D, int H, int W,
@@ -90,7 +92,8 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
     int aoff[C::AM];
 #pragma unroll
     for (int a = 0; a < C::AM; ++a) {
-        const int m = (wm * C::AM + a) * 32 + li;
+        int m = (wm * C::AM + a) * 32 + li;
+        if (m >= C::M) m = 0;                  // padding row: reads a valid voxel, never stored
         const int dz = m / (BH * BW), dy = (m / BW) % BH, dx = m % BW;
         aoff[a] = ((dz * C::HH + dy) * C::HW + dx) * C::CKP + 4 * lh;
     }
@@ -104,12 +107,12 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
     // The halo of chunk cc+1 is fetched into registers while chunk cc is being multiplied, and
     // only written to LDS between the two barriers: global-memory latency stays off the
     // critical path of the block.
-    constexpr int NH = (C::HV * 2 + 255) / 256;
+    constexpr int NH = (C::HV * 2 + C::NTHR - 1) / C::NTHR;
     float4 hreg[NH];
     auto load_halo = [&](int c0) {
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
-            const int idx = tid + 256 * i;
+            const int idx = tid + C::NTHR * i;
             const int hv = idx >> 1, q = idx & 1;
             const int hx = hv % C::HW, hy = (hv / C::HW) % C::HH, hz = hv / (C::HW * C::HH);
             const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
         if (!(SIV_EXP & 16)) __syncthreads();  // previous chunk's MFMAs are done with the halo
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
-            const int idx = tid + 256 * i;
+            const int idx = tid + C::NTHR * i;
             if ((idx >> 1) < C::HV && (!(SIV_EXP & 32) || hreg[i].x == 123.f))
                 *reinterpret_cast<float4*>(hal + (idx >> 1) * C::CKP + 4 * (idx & 1)) = hreg[i];
         }
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
                     const int gz = z0 + m / (BH * BW), gy = y0 + (m / BW) % BH, gx = x0 + m % BW;
                     float4 v = *reinterpret_cast<const float4*>(tile + row * C::EPI_STRIDE + 4 * cq);
                     v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
-                    if (gz < D && gy < H && gx < W && co < Cout && (!(SIV_EXP & 8) || v.x == 123.f))
+                    if (m < C::M && gz < D && gy < H && gx < W && co < Cout && (!(SIV_EXP & 8) || v.x == 123.f))
                         *reinterpret_cast<float4*>(y + ((((long)n * D + gz) * H + gy) * W + gx) * Cout + co) = v;
                 }
             }
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void k3_fwd_mfma(const float* __restrict__ x,
             for (int r = 0; r < 16; ++r) {
                 const int m = (wm * C::AM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int gz = z0 + m / (BH * BW), gy = y0 + (m / BW) % BH, gx = x0 + m % BW;
-                if (gz < D && gy < H && gx < W && (!(SIV_EXP & 8) || acc[a][bb][r] == 123.f))
+                if (m < C::M && gz < D && gy < H && gx < W && (!(SIV_EXP & 8) || acc[a][bb][r] == 123.f))
                     y[((((long)n * D + gz) * H + gy) * W + gx) * Cout + co] = acc[a][bb][r] + bv;
             }
         }
@@ -270,7 +273,7 @@ static int launch_fwd(const float* x, const float* wp, const float* bias, float*
         return SIV_EINVAL;
     }
     k3_fwd_mfma<BD, BH, BW, WM, WN, NT, UPS>
-        <<<dim3((unsigned)nblk, (unsigned)((Cout + NT - 1) / NT)), 256, C::LDS_BYTES, s>>>(
+        <<<dim3((unsigned)nblk, (unsigned)((Cout + NT - 1) / NT)), C::NTHR, C::LDS_BYTES, s>>>(
             x, wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
     SIV_CHECK_LAUNCH("conv3d_k3(mfma)");
     return SIV_OK;
@@ -279,13 +282,15 @@ static int launch_fwd(const float* x, const float* wp, const float* bias, float*
 // Channel counts the matrix-core path takes: 16-byte channel groups on the input side, anything
 // on the output side (tiles of 32 or 64 output channels, zero padded).
 bool k3_fwd_mfma_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cin >= 4 && Cout >= 8; }
-static int fwd_tile(int Cout) { return Cout % 64 == 0 ? 64 : 32; }
-size_t k3_fwd_mfma_ws_bytes(int Cin, int Cout) {
-    const int NT = fwd_tile(Cout);
-    return ((size_t)((Cout + NT - 1) / NT) * ((Cin + 7) / 8) * 27 * NT * 8 + 512) * sizeof(float);
-}
 
-// Volumes whose bricks would be mostly padding use the small brick.
+// Brick / wave tiling per problem shape.
+//   kBig    4x8x8 bricks, 4 waves x (2x2) accumulators: the full-resolution and 40x48x40 layers
+//   kSmall  2x4x8 bricks: volumes the big brick would mostly pad
+//   kW10b   2x4x10 bricks (80 rows padded to 96), 3 waves x (1x1), 32-channel tiles: volumes 10
+//           wide (10x12x10).  (A 2x8x10 / 5-wave variant for 20x24x20 measured 25 % slower than
+//           kBig with its padded third brick column, and is not instantiated.)
+//   kN32    4x8x8 bricks with 32-channel tiles: output widths that are not multiples of 64
+enum FwdKind { kBig, kSmall, kW10b, kN32 };
 static bool use_small_brick(int D, int H, int W) {
     auto waste = [&](int bd, int bh, int bw) {
         const double full = (double)((D + bd - 1) / bd * bd) * ((H + bh - 1) / bh * bh) *
@@ -293,6 +298,15 @@ static bool use_small_brick(int D, int H, int W) {
         return full / ((double)D * H * W);
     };
     return waste(2, 4, 8) * 1.15 < waste(4, 8, 8);
+}
+static FwdKind fwd_kind(int D, int H, int W, int Cout) {
+    if (Cout % 64 != 0) return kN32;
+    if (W == 10) return kW10b;
+    return use_small_brick(D, H, W) ? kSmall : kBig;
+}
+static int fwd_tile(FwdKind k) { return (k == kN32 || k == kW10b) ? 32 : 64; }
+size_t k3_fwd_mfma_ws_bytes(int Cin, int Cout) {   // upper bound over both tile widths
+    return ((size_t)((Cout + 31) / 32) * ((Cin + 7) / 8) * 27 * 32 * 8 + 512) * sizeof(float);
 }
 
 // `w` is the convolution's weight tensor; flip selects forward (0) or input-gradient (1) use.
@@ -302,18 +316,22 @@ int k3_fwd_mfma_launch(const float* x, const float* w, const float* bias, float*
                        hipStream_t s) {
     SIV_CHECK_WS(k3_fwd_mfma_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(mfma)");
     float* wp = (float*)ws;
-    const int NT = fwd_tile(Cout);
+    const FwdKind kind = fwd_kind(D, H, W, Cout);
+    const int NT = fwd_tile(kind);
     const long total = (long)((Cout + NT - 1) / NT) * ((Cin + 7) / 8) * 27 * NT * 8;
     long g = cdiv(total, 256);
     if (g > 4096) g = 4096;
     k3_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout, NT, flip);
     SIV_CHECK_LAUNCH("conv3d_k3(pack weights)");
-    const bool small = NT == 64 && use_small_brick(D, H, W);
 #define SIV_FWD(BD, BH, BW, WM, WN, NTT)                                                              \
     (ups == 1 ? launch_fwd<BD, BH, BW, WM, WN, NTT, 1>(x, wp, bias, y, N, D, H, W, Cin, Cout, s)       \
               : launch_fwd<BD, BH, BW, WM, WN, NTT, 2>(x, wp, bias, y, N, D, H, W, Cin, Cout, s))
-    if (NT == 32) return SIV_FWD(4, 8, 8, 4, 1, 32);
-    return small ? SIV_FWD(2, 4, 8, 2, 2, 64) : SIV_FWD(4, 8, 8, 4, 1, 64);
+    switch (kind) {
+        case kN32: return SIV_FWD(4, 8, 8, 4, 1, 32);
+        case kW10b: return SIV_FWD(2, 4, 10, 3, 1, 32);
+        case kSmall: return SIV_FWD(2, 4, 8, 2, 2, 64);
+        default: return SIV_FWD(4, 8, 8, 4, 1, 64);
+    }
 #undef SIV_FWD
 }
 

@@ -335,14 +335,18 @@ __global__ __launch_bounds__(256) void thin_wg_k(const float* __restrict__ a,
 
 // mode 0 (stem): dw[c*27+tap] = T[c][tap], dbias[c] = T[c][27]
 // mode 1 (tail): dw[(26-tap)*C+c] = T[c][tap]
+// One wave per output element: lanes stride over the per-block partials, fixed-order wave sum.
 __global__ __launch_bounds__(256) void thin_wg_reduce(const float* __restrict__ part, int nblk, int C,
                                                       int mode, float* __restrict__ dw,
                                                       float* __restrict__ dbias, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= C * 28) return;
     const int c = i / 28, t = i % 28;
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(long)b * C * 28 + i];
+    for (int b = lane; b < nblk; b += 64) s += (double)part[(long)b * C * 28 + i];
+    s = wave_sum_d(s);
+    if (lane != 0) return;
     float* dst = nullptr;
     if (t < 27) dst = mode == 0 ? dw + c * 27 + t : dw + (26 - t) * C + c;
     else if (mode == 0 && dbias) dst = dbias + c;
@@ -420,7 +424,7 @@ int k3_thin_wgrad_launch(const float* x, const float* dy, float* dw, float* dbia
     const float* g = mode == 0 ? dy : x;
     thin_wg_k<<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb);
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(thin)");
-    thin_wg_reduce<<<(C * 28 + 255) / 256, 256, 0, s>>>(part, (int)nblk, C, mode, dw, dbias, accumulate);
+    thin_wg_reduce<<<(C * 28 + 3) / 4, 256, 0, s>>>(part, (int)nblk, C, mode, dw, dbias, accumulate);
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(thin reduce)");
     if (mode == 1 && dbias) {
         float* p2 = (float*)((char*)ws + part_bytes);

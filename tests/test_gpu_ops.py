@@ -72,6 +72,9 @@ CONV_CASES = [
     (12, 24, (8, 12, 8), 2, 1, 0), (16, 16, (9, 10, 11), 1, 1, 0), (24, 12, (8, 12, 8), 1, 2, 0),
     (48, 32, (4, 8, 8), 2, 1, 0), (32, 48, (5, 6, 5), 3, 1, 0), (128, 16, (4, 8, 8), 1, 1, 0),
     (4, 8, (8, 8, 8), 1, 1, 0), (20, 100, (4, 4, 8), 1, 1, 0),
+    # widths 10 / 20 (the two deepest levels of an 80x96x80 input): 10-wide bricks in 3-wave blocks
+    (8, 64, (10, 24, 20), 1, 1, 0), (16, 64, (10, 24, 20), 1, 2, 0), (8, 128, (5, 12, 10), 2, 1, 0),
+    (64, 64, (10, 12, 10), 1, 1, 0), (8, 64, (4, 6, 10), 1, 2, 0),
     # the same wide shapes through the generic kernels (cross-check of the dispatcher)
     (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
 ]
