@@ -99,6 +99,22 @@ int siv_add_act_fwd(const float* a, const float* b, float slope, float* out, lon
 int siv_add_act_bwd(const float* dout, const float* a, const float* b, float slope, float* d,
                     long n, siv_stream_t stream);
 
+/* ---- input pipeline ------------------------------------------------------------------
+ * siv_preprocess: BrainDataset._preprocess of utils/data_load.py:25-30 for a batch of B raw
+ * volumes of n voxels each: v = clip(v, 0, cut_range * std(v)) (population std, cut_range = 4
+ * in the reference), then (v - min(v)) / (max(v) - min(v)); a constant volume yields NaN as
+ * numpy does.  voxels and out are [B][n] fp32 and must not overlap. */
+int siv_preprocess(const float* voxels, float* out, int B, long n, float cut_range,
+                   void* ws, size_t ws_bytes, siv_stream_t stream);
+/* siv_flip_shift: per-volume axis flips and integer shifts with zero fill, the flip/shift
+ * augmentation the 160x192x160 benchmark configuration names.  It stands in the slot of the
+ * transform applied before _preprocess at utils/data_load.py:21-22 (the reference fills that slot
+ * with torchio's RandomAffine, aug-z-1200main.py:106-119).  params is int[B][6] on the device:
+ * flipD, flipH, flipW (0/1), shiftD, shiftH, shiftW (voxels, toward larger indices; the flip is
+ * applied first).  in and out are [B][D][H][W] fp32 and must not alias. */
+int siv_flip_shift(const float* in, const int* params, float* out, int B, int D, int H, int W,
+                   siv_stream_t stream);
+
 /* ---- BatchNorm3d (+ residual + activation + AvgPool3d + Dropout) ----------------
  * siv_bn_stats: training-mode batch statistics of nn.BatchNorm3d (models/models.py:18,22,
  * 56,60,93,119): per-channel mean and BIASED variance over the M = N*D*H*W rows of y,

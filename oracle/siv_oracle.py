@@ -515,3 +515,38 @@ def bn_act(y: Tensor, gamma: Tensor, beta: Tensor, running_mean: Tensor, running
     if keep is not None:
         h = h * keep * (1.0 / (1.0 - p))
     return h
+
+
+# --------------------------------------------------------------------------
+# input pipeline
+# --------------------------------------------------------------------------
+def preprocess(voxel, cut_range: float = 4.0):
+    """BrainDataset._preprocess + normalize -- utils/data_load.py:25-30, 36-37 (numpy, as the
+    reference): clip to [0, cut_range * std], min-max to [0, 1], add the channel axis, float32."""
+    import numpy as np
+    voxel = np.clip(voxel, 0, cut_range * np.std(voxel))
+    lo, hi = np.min(voxel), np.max(voxel)
+    voxel = (voxel - lo) / (hi - lo)
+    return voxel[np.newaxis, ].astype("f")
+
+
+def flip_shift(vol, flips, shifts):
+    """Definition of the flip/shift augmentation (no reference counterpart runs here: the
+    reference's augmentation is torchio's RandomAffine, aug-z-1200main.py:106-119, and torchio
+    is not installed -- parity unpinned).  vol: (D, H, W) numpy; each flagged axis is reversed,
+    then the volume is shifted by `shifts` voxels toward larger indices with zero fill."""
+    import numpy as np
+    out = vol
+    for ax, f in enumerate(flips):
+        if f:
+            out = np.flip(out, axis=ax)
+    res = np.zeros_like(out)
+    src, dst = [], []
+    for ax, sft in enumerate(shifts):
+        n = out.shape[ax]
+        if abs(sft) >= n:
+            return res
+        src.append(slice(max(0, -sft), min(n, n - sft)))
+        dst.append(slice(max(0, sft), min(n, n + sft)))
+    res[tuple(dst)] = out[tuple(src)]
+    return res

@@ -197,6 +197,34 @@ class HipBackend:
                                             self._stream(a)), "siv_add_act_bwd")
         return d
 
+    # ---- input pipeline ------------------------------------------------------------------
+    def preprocess(self, voxels, cut_range: float = 4.0):
+        """(B, D, H, W) or (B, 1, D, H, W) raw fp32 volumes -> (B, 1, D, H, W) normalised."""
+        self._check_dev(voxels)
+        v = voxels.contiguous()
+        if v.dim() == 5:
+            assert v.shape[1] == 1, tuple(v.shape)
+            v = v[:, 0]
+        B, D, H, W = v.shape
+        out = torch.empty((B, 1, D, H, W), device=v.device, dtype=torch.float32)
+        ws, wsb = self._workspace(v)
+        _lib.check(self.lib.siv_preprocess(_p(v), _p(out), B, D * H * W, float(cut_range), ws, wsb,
+                                           self._stream(v)), "siv_preprocess")
+        return out
+
+    def flip_shift(self, voxels, params):
+        """params: int32 (B, 6) device tensor = flipD, flipH, flipW, shiftD, shiftH, shiftW."""
+        self._check_dev(voxels)
+        v = voxels.contiguous()
+        shape = v.shape
+        B, (D, H, W) = shape[0], shape[-3:]
+        assert v.numel() == B * D * H * W, tuple(shape)
+        assert params.is_cuda and params.dtype == torch.int32 and tuple(params.shape) == (B, 6)
+        out = torch.empty_like(v)
+        _lib.check(self.lib.siv_flip_shift(_p(v), _p(params.contiguous()), _p(out), B, D, H, W,
+                                           self._stream(v)), "siv_flip_shift")
+        return out
+
     # ---- batch norm + activation tail --------------------------------------------
     def bn_stats(self, y, running_mean, running_var, nbt, momentum: float):
         self._check_dev(y, running_mean, running_var, nbt)

@@ -203,3 +203,22 @@ def test_g7_fc_model_and_step():
             close(sd[k], ref_sd[k], rtol=1e-5,
                   atol=(2 * (step + 1) * hp.lr if noise_g else 2e-6), what=f"s{step}.sd.{k}")
     assert draws.i == int(g["n_draws"])
+
+
+@pytest.mark.parametrize("name", ["brain_f32", "signed_f32", "f64", "i16"])
+def test_g10_preprocess(name):
+    """utils/data_load.py BrainDataset._preprocess (fixture from the imported reference)."""
+    g = load("g10_preprocess.npz")
+    out = O.preprocess(g["in." + name])
+    assert out.dtype == np.float32 and out.shape == g["out." + name].shape
+    np.testing.assert_array_equal(out, g["out." + name])
+
+
+def test_flip_shift_definition():
+    v = np.arange(2 * 3 * 4, dtype=np.float32).reshape(2, 3, 4)
+    np.testing.assert_array_equal(O.flip_shift(v, (0, 0, 0), (0, 0, 0)), v)
+    np.testing.assert_array_equal(O.flip_shift(v, (0, 0, 1), (0, 0, 0)), v[:, :, ::-1])
+    s = O.flip_shift(v, (0, 0, 0), (0, 1, -2))
+    assert (s[:, 0] == 0).all() and (s[:, :, 2:] == 0).all()
+    np.testing.assert_array_equal(s[:, 1:, :2], v[:, :2, 2:])
+    assert (O.flip_shift(v, (1, 1, 1), (2, 0, 0)) == 0).all()

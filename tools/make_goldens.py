@@ -540,7 +540,43 @@ def g9_train_fc():
     print("g9_train_fc", {k: v for k, v in zip(("tE", "tD", "vE", "vD"), res)}, "draws", draws.i)
 
 
-ALL = {"g7": g7_fc, "g9": g9_train_fc, "g2": g2_blocks, "g3": g3_model, "g4": g4_step, "g5": g5_losses, "g6": g6_vae, "g8": g8_train}
+# ---------------------------------------------------------------- G10 input pipeline
+def g10_preprocess():
+    """BrainDataset._preprocess of utils/data_load.py on synthetic raw volumes: brain-like
+    (background zeros + bright outliers), negative values, float64 and int16 inputs."""
+    mod = types.ModuleType("datasets")
+    sub = types.ModuleType("datasets.dataset")
+    sub.CLASS_MAP = {}
+    saved = {k: sys.modules.get(k) for k in ("datasets", "datasets.dataset")}
+    sys.modules["datasets"], sys.modules["datasets.dataset"] = mod, sub     # unused import of the module
+    try:
+        import utils.data_load as DL
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    rs = np.random.RandomState(110)
+    shape = (20, 24, 16)
+    zz, yy, xx = np.meshgrid(*[np.linspace(-1, 1, n) for n in shape], indexing="ij")
+    mask = (zz ** 2 + yy ** 2 + xx ** 2) < 0.7
+    vols = {
+        "brain_f32": (mask * (300 + 80 * rs.randn(*shape)) + (rs.rand(*shape) > 0.999) * 5000).astype(np.float32),
+        "signed_f32": (rs.randn(*shape) * 2 + 0.5).astype(np.float32),
+        "f64": np.abs(rs.randn(*shape) * 100),
+        "i16": (mask * rs.randint(0, 4000, shape)).astype(np.int16),
+    }
+    ds = DL.BrainDataset([], [])
+    out = {}
+    for k, v in vols.items():
+        out["in." + k] = v
+        out["out." + k] = ds._preprocess(v)
+    np.savez_compressed(os.path.join(OUT, "g10_preprocess.npz"), **out)
+    print("g10_preprocess", {k: (v.dtype, v.shape) for k, v in out.items() if k.startswith("out.")})
+
+
+ALL = {"g10": g10_preprocess, "g7": g7_fc, "g9": g9_train_fc, "g2": g2_blocks, "g3": g3_model, "g4": g4_step, "g5": g5_losses, "g6": g6_vae, "g8": g8_train}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
