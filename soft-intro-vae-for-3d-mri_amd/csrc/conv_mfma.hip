@@ -100,9 +100,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k3_fwd_mfma(const float* __restr
     // this lane's B fragment inside a packed [64][8] tap slice: co = (wn*AN + bb)*32 + li, ci 4*lh..
     const float* wlane = wp + (long)blockIdx.y * nchunk * 27 * C::SLICE + (wn * C::AN * 32 + li) * 8 + 4 * lh;
 
-    float4 bnext[C::AN];
+    // weight fragments are fetched two taps ahead of their MFMAs: global loads return in order,
+    // so a fragment load issued behind the (HBM-latency) halo prefetch of the next chunk needs
+    // that much slack not to stall the matrix pipe
+    float4 bn1[C::AN], bn2[C::AN];
 #pragma unroll
-    for (int bb = 0; bb < C::AN; ++bb) bnext[bb] = *reinterpret_cast<const float4*>(wlane + bb * 256);
+    for (int bb = 0; bb < C::AN; ++bb) {
+        bn1[bb] = *reinterpret_cast<const float4*>(wlane + bb * 256);
+        bn2[bb] = *reinterpret_cast<const float4*>(wlane + C::SLICE + bb * 256);
+    }
 
     // The halo of chunk cc+1 is fetched into registers while chunk cc is being multiplied, and
     // only written to LDS between the two barriers: global-memory latency stays off the
@@ -150,14 +156,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k3_fwd_mfma(const float* __restr
         for (int t = 0; t < 27; ++t) {
             float4 bv[C::AN], av[C::AM];
 #pragma unroll
-            for (int bb = 0; bb < C::AN; ++bb) bv[bb] = bnext[bb];
+            for (int bb = 0; bb < C::AN; ++bb) {
+                bv[bb] = bn1[bb];
+                bn1[bb] = bn2[bb];
+            }
 #pragma unroll
             for (int a = 0; a < C::AM; ++a) av[a] = anext[a];
-            // prefetch the next tap's fragments (the first tap of the next chunk after the last one;
-            // the packed buffer carries one slice of padding so that this never leaves it)
+            // prefetch the fragments of tap t+2 (running into the next chunk at the end of this
+            // one; the packed buffer carries two slices of padding so that this never leaves it)
 #pragma unroll
             for (int bb = 0; bb < C::AN; ++bb)
-                if (!(SIV_EXP & 1)) bnext[bb] = *reinterpret_cast<const float4*>(wc + (t + 1) * C::SLICE + bb * 256);
+                if (!(SIV_EXP & 1)) bn2[bb] = *reinterpret_cast<const float4*>(wc + (t + 2) * C::SLICE + bb * 256);
             if (t + 1 < 27) {
                 const int t1 = t + 1;
                 const int tapoff = (((t1 / 9) * C::HH + (t1 / 3) % 3) * C::HW + t1 % 3) * C::CKP;
@@ -285,10 +294,13 @@ bool k3_fwd_mfma_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cin >= 4 
 
 // Brick / wave tiling per problem shape.
 //   kBig    4x8x8 bricks, 4 waves x (2x2) accumulators: the full-resolution and 40x48x40 layers
+//           (8x8x8 bricks with 4x2 accumulators per wave halve the weight-fragment loads per MFMA
+//           but drop to 2 waves per SIMD: measured +1 %, not kept)
 //   kSmall  2x4x8 bricks: volumes the big brick would mostly pad
 //   kW10b   2x4x10 bricks (80 rows padded to 96), 3 waves x (1x1), 32-channel tiles: volumes 10
-//           wide (10x12x10).  (A 2x8x10 / 5-wave variant for 20x24x20 measured 25 % slower than
-//           kBig with its padded third brick column, and is not instantiated.)
+//           wide (10x12x10).  (5-wave 2x8x10 and 4x8x10 variants for 20x24x20 measured 20-25 % slower
+//           than kBig with its padded third brick column -- five waves do not spread evenly over
+//           four SIMDs -- and are not instantiated.)
 //   kN32    4x8x8 bricks with 32-channel tiles: output widths that are not multiples of 64
 enum FwdKind { kBig, kSmall, kW10b, kN32 };
 static bool use_small_brick(int D, int H, int W) {
@@ -306,7 +318,7 @@ static FwdKind fwd_kind(int D, int H, int W, int Cout) {
 }
 static int fwd_tile(FwdKind k) { return (k == kN32 || k == kW10b) ? 32 : 64; }
 size_t k3_fwd_mfma_ws_bytes(int Cin, int Cout) {   // upper bound over both tile widths
-    return ((size_t)((Cout + 31) / 32) * ((Cin + 7) / 8) * 27 * 32 * 8 + 512) * sizeof(float);
+    return ((size_t)((Cout + 31) / 32) * ((Cin + 7) / 8) * 27 * 32 * 8 + 1024) * sizeof(float);
 }
 
 // `w` is the convolution's weight tensor; flip selects forward (0) or input-gradient (1) use.
