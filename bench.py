@@ -92,6 +92,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # keep stdout for the one JSON line: library banners (RCCL prints its version on the first
+    # communicator) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import siv.backend as sb
     import siv.rng as srng
     import siv.utils.my_trainer as trainer
@@ -142,8 +148,10 @@ def main():
         noise = srng.get_rng().eps(net.latent_shape(real.size(0), DIMS), device)
         return step(real, noise)
 
+    multi = dist.is_initialized()       # world > 1, or a forced one-rank rehearsal of the RCCL path
+
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -158,7 +166,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     recording["on"] = False
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -198,8 +206,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        print(json.dumps(out), flush=True)
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -26,16 +26,25 @@ def env_world():
         int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def _forced() -> bool:
+    """SIV_FORCE_COLLECTIVE=1 runs the rendezvous and the all-reduce path even at world size 1,
+    so that the RCCL code path can be rehearsed on a one-GPU machine."""
+    return os.environ.get("SIV_FORCE_COLLECTIVE") == "1" and "MASTER_ADDR" in os.environ
+
+
 def init_process_group(backend: str = None):
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
     'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _forced()) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
 
@@ -46,7 +55,8 @@ class GradSync:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.side = None
-        if self.world > 1 and device is not None and torch.device(device).type == "cuda":
+        self.collective = self.world > 1 or (_forced() and dist.is_initialized())
+        if self.collective and device is not None and torch.device(device).type == "cuda":
             self.side = torch.cuda.Stream(device=device)
 
     def shard(self, batch: torch.Tensor) -> torch.Tensor:
@@ -60,7 +70,7 @@ class GradSync:
         return batch[self.rank * per:(self.rank + 1) * per]
 
     def average_(self, flat_g: torch.Tensor) -> None:
-        if self.world == 1:
+        if not self.collective:
             return
         if self.side is not None:
             main = torch.cuda.current_stream(flat_g.device)
