@@ -45,12 +45,14 @@ __global__ __launch_bounds__(256) void one_to_c_k(const float* __restrict__ a,
                                                   const float* __restrict__ w,
                                                   const float* __restrict__ bias,
                                                   float* __restrict__ out, int N, int D, int H, int W,
-                                                  int C, int flip, int nbd, int nbh, int nbw) {
+                                                  int C, int flip, int nbd, int nbh, int nbw,
+                                                  int bricks_per_block, int nbricks) {
     __shared__ float hal[TH_V];
     const int QC = C >> 2;
     const int lanes = 256 / QC;
     const int q = threadIdx.x % QC, vl = threadIdx.x / QC;
     const bool active = vl < lanes;
+    // the weights are loaded once and reused for every brick of the block
     float4 wr[27];
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
@@ -65,26 +67,31 @@ __global__ __launch_bounds__(256) void one_to_c_k(const float* __restrict__ a,
         }
         if (bias) bv = *reinterpret_cast<const float4*>(bias + 4 * q);
     }
-    int n, z0, y0, x0;
-    brick_coords(blockIdx.x, nbd, nbh, nbw, n, z0, y0, x0);
-    load_halo1(a, hal, n, z0, y0, x0, D, H, W);
-    __syncthreads();
-    if (!active) return;
-    for (int m = vl; m < TB_V; m += lanes) {
-        const int dz = m >> 6, dy = (m >> 3) & 7, dx = m & 7;
-        const int gz = z0 + dz, gy = y0 + dy, gx = x0 + dx;
-        if (gz >= D || gy >= H || gx >= W) continue;
-        const float* hp = hal + (dz * TH_H + dy) * TH_W + dx;
-        float4 acc = bv;
+    const int b0 = blockIdx.x * bricks_per_block;
+    const int b1 = b0 + bricks_per_block < nbricks ? b0 + bricks_per_block : nbricks;
+    for (int br = b0; br < b1; ++br) {
+        int n, z0, y0, x0;
+        brick_coords(br, nbd, nbh, nbw, n, z0, y0, x0);
+        __syncthreads();
+        load_halo1(a, hal, n, z0, y0, x0, D, H, W);
+        __syncthreads();
+        if (!active) continue;
+        for (int m = vl; m < TB_V; m += lanes) {
+            const int dz = m >> 6, dy = (m >> 3) & 7, dx = m & 7;
+            const int gz = z0 + dz, gy = y0 + dy, gx = x0 + dx;
+            if (gz >= D || gy >= H || gx >= W) continue;
+            const float* hp = hal + (dz * TH_H + dy) * TH_W + dx;
+            float4 acc = bv;
 #pragma unroll
-        for (int t = 0; t < 27; ++t) {
-            const float av = hp[((t / 9) * TH_H + (t / 3) % 3) * TH_W + t % 3];
-            acc.x = fmaf(av, wr[t].x, acc.x);
-            acc.y = fmaf(av, wr[t].y, acc.y);
-            acc.z = fmaf(av, wr[t].z, acc.z);
-            acc.w = fmaf(av, wr[t].w, acc.w);
+            for (int t = 0; t < 27; ++t) {
+                const float av = hp[((t / 9) * TH_H + (t / 3) % 3) * TH_W + t % 3];
+                acc.x = fmaf(av, wr[t].x, acc.x);
+                acc.y = fmaf(av, wr[t].y, acc.y);
+                acc.z = fmaf(av, wr[t].z, acc.z);
+                acc.w = fmaf(av, wr[t].w, acc.w);
+            }
+            *reinterpret_cast<float4*>(out + ((((long)n * D + gz) * H + gy) * W + gx) * C + 4 * q) = acc;
         }
-        *reinterpret_cast<float4*>(out + ((((long)n * D + gz) * H + gy) * W + gx) * C + 4 * q) = acc;
     }
 }
 
@@ -387,16 +394,30 @@ int k3_thin_fwd_launch(const float* a, const float* w, const float* bias, float*
         set_error("conv3d_k3(thin): too many bricks");
         return SIV_EINVAL;
     }
+    // several bricks per block amortise the per-block weight loads; keep >= ~2000 blocks
+    int bpb = (int)(nblk / 2048);
+    if (bpb < 1) bpb = 1;
+    if (bpb > 8) bpb = 8;
+    const int nbr = (int)nblk;
+    if (Ca == 1) {
+        one_to_c_k<<<(unsigned)cdiv(nblk, bpb), 256, 0, s>>>(a, w, bias, out, N, D, H, W, Cb, flip, nbd, nbh,
+                                                             nbw, bpb, nbr);
+        SIV_CHECK_LAUNCH("conv3d_k3(thin)");
+        return SIV_OK;
+    }
+    // the matrix-core kernel runs one brick per block: with several, the barrier between the GEMM and
+    // the gather phase of a brick serialises what independent blocks otherwise overlap (measured)
+    const unsigned grid = (unsigned)nblk;
     if (Ca == 1)
-        one_to_c_k<<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, Cb, flip, nbd, nbh, nbw);
+        ;
     else if (Ca == 64)
-        c_to_one_mfma_k<8><<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nbd, nbh, nbw);
+        c_to_one_mfma_k<8><<<grid, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nbd, nbh, nbw);
     else if (Ca == 32)
-        c_to_one_mfma_k<4><<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nbd, nbh, nbw);
+        c_to_one_mfma_k<4><<<grid, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nbd, nbh, nbw);
     else if (Ca == 16)
-        c_to_one_mfma_k<2><<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nbd, nbh, nbw);
+        c_to_one_mfma_k<2><<<grid, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nbd, nbh, nbw);
     else if (Ca == 8)
-        c_to_one_mfma_k<1><<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nbd, nbh, nbw);
+        c_to_one_mfma_k<1><<<grid, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nbd, nbh, nbw);
     else
         c_to_one_k<<<(unsigned)nblk, 256, 0, s>>>(a, w, bias, out, N, D, H, W, Ca, flip, nbd, nbh, nbw);
     SIV_CHECK_LAUNCH("conv3d_k3(thin)");

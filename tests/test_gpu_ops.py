@@ -1,7 +1,7 @@
 """Per-operator parity: every libsiv entry point, called through the C ABI (ctypes) on a real
 MI355X, against the CPU oracle on the same seeded inputs.
 
-Tolerance (the bar BASELINE.json's north_star states): 1e-4 relative fp32, measured as
+Tolerance (the bar this build is held to): 1e-4 relative fp32, measured as
 max|hip - oracle| <= 1e-4 * max|oracle| per output tensor.  The backward of the BN/activation
 tail contains LeakyReLU/ReLU kinks: an element whose pre-activation is within rounding of zero
 may legitimately take the other branch, so those comparisons allow a handful of outlier
