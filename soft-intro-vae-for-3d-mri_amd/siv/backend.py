@@ -42,19 +42,30 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.load()
         self._ws = {}
+        self._side = {}
 
     # ---- plumbing ------------------------------------------------------------
     def _stream(self, t: torch.Tensor) -> int:
         return torch.cuda.current_stream(t.device).cuda_stream
 
     def _workspace(self, t: torch.Tensor) -> Tuple[int, int]:
-        dev = t.device
-        ws = self._ws.get(dev)
+        # one workspace per (device, stream): calls on different streams may overlap
+        key = (t.device, torch.cuda.current_stream(t.device).cuda_stream)
+        ws = self._ws.get(key)
         if ws is None:
             nbytes = int(self.lib.siv_workspace_bytes())
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self._ws[dev] = ws
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
+            self._ws[key] = ws
         return ws.data_ptr(), ws.numel()
+
+    def side_stream(self, device) -> "torch.cuda.Stream":
+        """A second stream per device on which an independent kernel (the weight gradient of a
+        layer, beside its input gradient) can run concurrently with the main stream."""
+        st = self._side.get(device)
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            self._side[device] = st
+        return st
 
     @staticmethod
     def _check_dev(*ts):
