@@ -15,7 +15,7 @@
 
 // SIV_EXP is a timing-only ablation mask used by tools/ubench (never set in the library build):
 // 1 = no weight-fragment loads, 2 = no LDS fragment reads, 4 = no halo staging,
-// 8 = no output stores, 16 = no block barriers, 32 = no LDS halo writes, 128 = scalar epilogue.
+// 8 = no output stores, 16 = no block barriers, 32 = no LDS halo writes, 128 = scalar epilogue, 256 = no XCD-aware brick order.
 #ifndef SIV_EXP
 #define SIV_EXP 0
 #endif
@@ -70,7 +70,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k3_fwd_mfma(const float* __restr
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave % WM, wn = wave / WM;
 
+    // Workgroups are handed to the 8 XCDs round-robin.  Remap the brick index so that each XCD (and
+    // its private L2) works through one contiguous eighth of the brick list: bricks that share halo
+    // voxels then run on the same L2 at about the same time.
     int b = blockIdx.x;
+    if (!(SIV_EXP & 256) && (gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
     const int bx = b % nbw; b /= nbw;
     const int by = b % nbh; b /= nbh;
     const int bz = b % nbd;

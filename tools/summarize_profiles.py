@@ -21,7 +21,8 @@ ALGO_FLOP = 2.0 * 27 * 64 * 64 * 80 * 96 * 80 * 8
 
 
 def one(pattern):
-    return glob.glob(os.path.join(SRC, pattern))[0]
+    """Newest match (gpurun merges successive runs into the same local directory)."""
+    return max(glob.glob(os.path.join(SRC, pattern)), key=os.path.getmtime)
 
 
 def counters(d):
