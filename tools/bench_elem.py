@@ -75,7 +75,7 @@ def main():
             report(f"{tag} conv C->1 wgrad", timeit(lambda: B.conv3d_k3_wgrad(y, d1, 1, True), a.reps), T)
             ad = torch.randn_like(y)
             report(f"{tag} act_dropout fwd", timeit(lambda: B.act_dropout_fwd(y, None, 0.0, 0.0), a.reps), 2 * T)
-            report(f"{tag} upsample2_bwd (via dgrad path n/a) sse", timeit(lambda: B.sse_fwd(y, ad), a.reps), 2 * T)
+            report(f"{tag} sse_fwd", timeit(lambda: B.sse_fwd(y, ad), a.reps), 2 * T)
 
 
 if __name__ == "__main__":
