@@ -255,6 +255,9 @@ def _dot(a, b):
     (1, 64, FULL, 2, 1),             # encoder stem
     (64, 1, FULL, 2, 1),             # decoder output layer
     (128, 128, (20, 24, 20), 2, 1), (256, 256, (10, 12, 10), 8, 1), (256, 128, (20, 24, 20), 1, 2),
+    # the 160x192x160 volumes of the augmented configuration: 1.26 GB tensors, > 2^28 elements
+    (64, 64, (160, 192, 160), 1, 1), (1, 64, (160, 192, 160), 1, 1), (64, 1, (160, 192, 160), 1, 1),
+    (64, 64, (80, 96, 80), 16, 1),     # batch 16: > 2^31 bytes per tensor
 ])
 def test_full_size_conv_adjoint_identities(cin, cout, dims, n, ups):
     """<conv(x,w), dy> == <x, dgrad(dy,w)> == <w, wgrad(x,dy)>: the three kernels of a layer must be
