@@ -1,0 +1,261 @@
+// 3x3x3 convolution, forward / input gradient, with the Winograd F(2,3) minimal-filtering
+// identity applied along W and the fp32 matrix cores doing the channel contraction.
+//
+// For two adjacent outputs y0, y1 of a row and the four inputs d0..d3 they depend on,
+//   y0 = m0 + m1 + m2,  y1 = m1 - m2 - m3,   with
+//   m0 = (d0 - d2) g0,  m1 = (d1 + d2)(g0 + g1 + g2)/2,  m2 = (d2 - d1)(g0 - g1 + g2)/2,  m3 = (d1 - d3) g2
+// so a 3-tap row costs 4 multiplications per output pair instead of 6: the 27 taps per output of
+// the direct kernel become 9 (kd,kh) x 4 positions per PAIR = 18 per output.  Everything stays
+// fp32; the only change in rounding is the additions of the two transforms (the /2 is exact).
+//
+//   M rows  = output pairs of a 4x8x8-voxel brick (128 pairs), N = 64 output channels
+//   K       = 9 (kd,kh) x Cin per Winograd position; 4 positions = 4 independent accumulators
+//
+// The input transform is applied while the halo is staged into LDS (V[pos][halo row][pair][ci]),
+// the weight transform when the weights are packed, the output transform on the accumulators.
+#include "siv_common.h"
+
+namespace siv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int UPS>
+struct WinoCfg {
+    static constexpr int BD = 4, BH = 8, BW = 8;
+    static constexpr int CK = 8, CKP = 12;
+    static constexpr int PW = BW / 2;                     // output pairs per brick row
+    static constexpr int M = BD * BH * PW;                // 128 rows
+    static constexpr int WM = 2, WN = 2, NW = 4, NTHR = 256;
+    static constexpr int NT = 64;
+    static constexpr int AM = (M / 32) / WM;              // 2 row tiles per wave, 1 column tile
+    static constexpr int HD = BD + 2, HH = BH + 2;
+    static constexpr int HP = HD * HH * PW;               // (halo row, pair) items: 240
+    static constexpr int PLANE = HP * CKP;                // floats of one Winograd position
+    static constexpr int V_FLOATS = 4 * PLANE;
+    static constexpr int TAPS = 36;                       // (kd, kh, pos)
+    static constexpr int SLICE = NT * 8;
+    static constexpr int EPI_STRIDE = 40, EPI_FLOATS = 32 * EPI_STRIDE;
+    static constexpr int LDS_FLOATS = V_FLOATS > NW * EPI_FLOATS ? V_FLOATS : NW * EPI_FLOATS;
+    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+    static constexpr int NH = (HP * 2 + NTHR - 1) / NTHR; // staging items per thread: 2
+};
+
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <int UPS>
+__global__ __launch_bounds__(256, 2) void k3_fwd_wino(const float* __restrict__ x,
+                                                      const float* __restrict__ wp,
+                                                      const float* __restrict__ bias,
+                                                      float* __restrict__ y, int N, int D, int H, int W,
+                                                      int Cin, int Cout, int nbd, int nbh, int nbw) {
+    using C = WinoCfg<UPS>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // each XCD walks one contiguous eighth of the brick list (bricks sharing halo voxels meet in one L2)
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    const int bx = b % nbw; b /= nbw;
+    const int by = b % nbh; b /= nbh;
+    const int bz = b % nbd;
+    const int n = b / nbd;
+    const int z0 = bz * C::BD, y0 = by * C::BH, x0 = bx * C::BW;
+    const int co0 = blockIdx.y * C::NT;
+    const int Di = D / UPS, Hi = H / UPS, Wi = W / UPS;
+    const int nchunk = (Cin + C::CK - 1) / C::CK;
+
+    f32x16 acc[4][C::AM];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int a = 0; a < C::AM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][a][r] = 0.f;
+
+    // LDS offset of this lane's A row (pair) for tap (0,0), position 0
+    int aoff[C::AM];
+#pragma unroll
+    for (int a = 0; a < C::AM; ++a) {
+        const int m = (wm * C::AM + a) * 32 + li;
+        const int dz = m / (C::BH * C::PW), dy = (m / C::PW) % C::BH, px = m % C::PW;
+        aoff[a] = ((dz * C::HH + dy) * C::PW + px) * C::CKP + 4 * lh;
+    }
+    // this lane's B fragment inside a packed [64 co][8 ci] slice
+    const float* wlane = wp + (long)blockIdx.y * nchunk * C::TAPS * C::SLICE + (wn * 32 + li) * 8 + 4 * lh;
+    float4 bn1 = *reinterpret_cast<const float4*>(wlane);
+    float4 bn2 = *reinterpret_cast<const float4*>(wlane + C::SLICE);
+
+    // halo staging: item = (halo row, pair, channel half); four raw inputs d0..d3 per item
+    float4 hreg[C::NH][4];
+    auto load_halo = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < C::NH; ++i) {
+            const int idx = tid + C::NTHR * i;
+            const int q = idx & 1, it = idx >> 1;
+            const int px = it % C::PW, hrow = it / C::PW;
+            const int hy = hrow % C::HH, hz = hrow / C::HH;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1;
+            const bool rowok = it < C::HP && c0 + 4 * q < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H;
+            const long rowbase = (((long)n * Di + gz / UPS) * Hi + gy / UPS) * Wi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gx = x0 + 2 * px - 1 + j;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rowok && gx >= 0 && gx < W)
+                    v = *reinterpret_cast<const float4*>(x + (rowbase + gx / UPS) * Cin + c0 + 4 * q);
+                hreg[i][j] = v;
+            }
+        }
+    };
+    load_halo(0);
+    for (int cc = 0; cc < nchunk; ++cc) {
+        __syncthreads();  // previous chunk's MFMAs are done with V
+#pragma unroll
+        for (int i = 0; i < C::NH; ++i) {
+            const int idx = tid + C::NTHR * i;
+            const int q = idx & 1, it = idx >> 1;
+            if (it < C::HP) {
+                float* dst = lds + it * C::CKP + 4 * q;
+                *reinterpret_cast<float4*>(dst) = f4sub(hreg[i][0], hreg[i][2]);
+                *reinterpret_cast<float4*>(dst + C::PLANE) = f4add(hreg[i][1], hreg[i][2]);
+                *reinterpret_cast<float4*>(dst + 2 * C::PLANE) = f4sub(hreg[i][2], hreg[i][1]);
+                *reinterpret_cast<float4*>(dst + 3 * C::PLANE) = f4sub(hreg[i][1], hreg[i][3]);
+            }
+        }
+        __syncthreads();
+        if (cc + 1 < nchunk) load_halo((cc + 1) * C::CK);
+        const float* wc = wlane + (long)cc * C::TAPS * C::SLICE;
+        float4 anext[C::AM];
+#pragma unroll
+        for (int a = 0; a < C::AM; ++a) anext[a] = *reinterpret_cast<const float4*>(lds + aoff[a]);
+#pragma unroll
+        for (int t = 0; t < C::TAPS; ++t) {
+            const int pos = t & 3;
+            float4 av[C::AM];
+            const float4 bv = bn1;
+            bn1 = bn2;
+#pragma unroll
+            for (int a = 0; a < C::AM; ++a) av[a] = anext[a];
+            bn2 = *reinterpret_cast<const float4*>(wc + (t + 2) * C::SLICE);
+            if (t + 1 < C::TAPS) {
+                const int t1 = t + 1;
+                const int tapoff = (t1 & 3) * C::PLANE + (((t1 / 12) * C::HH + (t1 / 4) % 3) * C::PW) * C::CKP;
+#pragma unroll
+                for (int a = 0; a < C::AM; ++a)
+                    anext[a] = *reinterpret_cast<const float4*>(lds + aoff[a] + tapoff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#define SIV_WSTEP(F)                                                                        \
+    _Pragma("unroll") for (int a = 0; a < C::AM; ++a)                                       \
+        acc[pos][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].F, bv.F, acc[pos][a], 0, 0, 0);
+            SIV_WSTEP(x)
+            SIV_WSTEP(y)
+            SIV_WSTEP(z)
+            SIV_WSTEP(w)
+#undef SIV_WSTEP
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // output transform + store: per row tile and output of the pair, transpose the 32x32 result
+    // through this wave's slice of LDS and write 16-byte channel runs
+    float* tile = lds + wave * C::EPI_FLOATS;
+    const int cq = lane & 7;
+    const int co = co0 + wn * 32 + 4 * cq;
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && co < Cout) bq = *reinterpret_cast<const float4*>(bias + co);
+#pragma unroll
+    for (int a = 0; a < C::AM; ++a) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = half == 0 ? (acc[0][a][r] + acc[1][a][r]) + acc[2][a][r]
+                                          : (acc[1][a][r] - acc[2][a][r]) - acc[3][a][r];
+                tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * C::EPI_STRIDE + li] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + (lane >> 3);
+                const int m = (wm * C::AM + a) * 32 + row;
+                const int gz = z0 + m / (C::BH * C::PW), gy = y0 + (m / C::PW) % C::BH;
+                const int gx = x0 + 2 * (m % C::PW) + half;
+                float4 v = *reinterpret_cast<const float4*>(tile + row * C::EPI_STRIDE + 4 * cq);
+                v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                if (gz < D && gy < H && gx < W && co < Cout)
+                    *reinterpret_cast<float4*>(y + ((((long)n * D + gz) * H + gy) * W + gx) * Cout + co) = v;
+            }
+        }
+    }
+}
+
+// Packed, transformed weights: wp[ct][cc][(kd,kh,pos)][co (64)][ci (8)], zero padded.
+//   flip == 0: g[kw] = w[kco][kd][kh][kw][kci]              (w is [Kout][27][Kin])
+//   flip == 1: g[kw] = w[kci][2-kd][2-kh][2-kw][kco]        (w is [Kin][27][Kout]; input gradient)
+__global__ __launch_bounds__(256) void k3_pack_weights_wino(const float* __restrict__ w,
+                                                            float* __restrict__ wp, int Kin, int Kout,
+                                                            int flip) {
+    const int nchunk = (Kin + 7) / 8, ntile = (Kout + 63) / 64;
+    const long total = (long)ntile * nchunk * 36 * 64 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        long r = i >> 3;
+        const int co = (int)(r & 63); r >>= 6;
+        const int t = (int)(r % 36); r /= 36;
+        const int cc = (int)(r % nchunk);
+        const int ct = (int)(r / nchunk);
+        const int pos = t & 3, kh = (t >> 2) % 3, kd = t / 12;
+        const int kco = ct * 64 + co, kci = cc * 8 + j;
+        float v = 0.f;
+        if (kco < Kout && kci < Kin) {
+            float g[3];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tap = (kd * 3 + kh) * 3 + kw;
+                g[kw] = flip ? w[((long)kci * 27 + (26 - tap)) * Kout + kco] : w[((long)kco * 27 + tap) * Kin + kci];
+            }
+            v = pos == 0 ? g[0] : pos == 1 ? 0.5f * ((g[0] + g[1]) + g[2]) : pos == 2 ? 0.5f * ((g[0] - g[1]) + g[2]) : g[2];
+        }
+        wp[i] = v;
+    }
+}
+
+bool k3_fwd_wino_supported(int Cin, int Cout) { return Cin % 8 == 0 && Cout % 64 == 0; }
+size_t k3_fwd_wino_ws_bytes(int Cin, int Cout) {
+    return ((size_t)((Cout + 63) / 64) * ((Cin + 7) / 8) * 36 * 512 + 1024) * sizeof(float);
+}
+
+int k3_fwd_wino_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H,
+                       int W, int Cin, int Cout, int ups, int flip, void* ws, size_t ws_bytes,
+                       hipStream_t s) {
+    SIV_CHECK_WS(k3_fwd_wino_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(winograd)");
+    float* wp = (float*)ws;
+    const long total = (long)((Cout + 63) / 64) * ((Cin + 7) / 8) * 36 * 512;
+    long g = cdiv(total, 256);
+    if (g > 4096) g = 4096;
+    k3_pack_weights_wino<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout, flip);
+    SIV_CHECK_LAUNCH("conv3d_k3(pack winograd weights)");
+    const int nbd = (D + 3) / 4, nbh = (H + 7) / 8, nbw = (W + 7) / 8;
+    const long nblk = (long)N * nbd * nbh * nbw;
+    if (nblk > 0x7fffffffL) {
+        set_error("conv3d_k3(winograd): too many bricks");
+        return SIV_EINVAL;
+    }
+    const dim3 grid((unsigned)nblk, (unsigned)(Cout / 64));
+    if (ups == 1)
+        k3_fwd_wino<1><<<grid, 256, WinoCfg<1>::LDS_BYTES, s>>>(x, wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
+    else
+        k3_fwd_wino<2><<<grid, 256, WinoCfg<2>::LDS_BYTES, s>>>(x, wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
+    SIV_CHECK_LAUNCH("conv3d_k3(winograd)");
+    return SIV_OK;
+}
+
+}  // namespace siv

@@ -7,6 +7,7 @@ namespace siv {
 
 static thread_local char g_err[512] = "";
 static int g_conv_path = 0;
+static const bool g_auto_wino = true;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -14,7 +15,7 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-int conv_path() { return g_conv_path; }
+int conv_path() { return g_conv_path == 4 ? 2 : g_conv_path; }
 
 // conv_generic.hip
 int k3_fwd_generic_launch(const float*, const float*, const float*, float*, int, int, int, int, int,
@@ -31,6 +32,10 @@ int k3_fwd_mfma_launch(const float*, const float*, const float*, float*, int, in
 bool k3_wgrad_mfma_supported(int Cin, int Cout);
 int k3_wgrad_mfma_launch(const float*, const float*, float*, int, int, int, int, int, int, int, int,
                          void*, size_t, hipStream_t);
+// conv_wino.hip
+bool k3_fwd_wino_supported(int Cin, int Cout);
+int k3_fwd_wino_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int,
+                       int, int, void*, size_t, hipStream_t);
 // conv_thin.hip
 bool k3_thin_supported(int Cin, int Cout);
 int k3_thin_fwd_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int,
@@ -50,6 +55,15 @@ static int check_conv_shape(const char* what, int N, int D, int H, int W, int Ci
     return SIV_OK;
 }
 
+// Winograd F(2,3) path: on request (path 3), or automatically (path 0) for volumes large enough to
+// fill the chip with 4x8x8 bricks.  Path 4 = matrix-core kernels without Winograd.
+static bool use_wino(int path, bool aligned, int N, int D, int H, int W, int Cin, int Cout) {
+    if (!aligned || !k3_fwd_wino_supported(Cin, Cout)) return false;
+    if (path == 3) return true;
+    if (path != 0) return false;
+    return g_auto_wino && (long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8) * (Cout / 64) >= 1024;
+}
+
 }  // namespace siv
 
 using namespace siv;
@@ -58,7 +72,7 @@ extern "C" const char* siv_last_error(void) { return g_err; }
 extern "C" int siv_version(void) { return 100; }
 extern "C" size_t siv_workspace_bytes(void) { return (size_t)512 << 20; }
 extern "C" int siv_set_conv_path(int path) {
-    SIV_CHECK_ARG(path >= 0 && path <= 2, "set_conv_path: path must be 0, 1 or 2");
+    SIV_CHECK_ARG(path >= 0 && path <= 4, "set_conv_path: path must be 0..4");
     g_conv_path = path;
     return SIV_OK;
 }
@@ -74,6 +88,8 @@ extern "C" int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bi
     const bool al = aligned16(x) && aligned16(w) && aligned16(y) && aligned16(ws);
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
         return k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s);
+    if (use_wino(path, al, N, D, H, W, Cin, Cout))
+        return k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s);
     if (path != 1 && al && k3_fwd_mfma_supported(Cin, Cout))
         return k3_fwd_mfma_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s);
     SIV_CHECK_ARG(path != 2, "conv3d_k3_fwd: no specialised kernel for Cin=%d Cout=%d ups=%d", Cin,
@@ -93,6 +109,8 @@ extern "C" int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx, i
     // dgrad is the forward convolution of dy with the flipped, transposed weights
     if (path != 1 && al && k3_thin_supported(Cout, Cin))
         return k3_thin_fwd_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, s);
+    if (use_wino(path, al, N, D, H, W, Cout, Cin))
+        return k3_fwd_wino_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s);
     if (path != 1 && al && k3_fwd_mfma_supported(Cout, Cin))
         return k3_fwd_mfma_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s);
     SIV_CHECK_ARG(path != 2, "conv3d_k3_dgrad: no specialised kernel for Cin=%d Cout=%d", Cin, Cout);

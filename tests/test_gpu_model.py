@@ -285,7 +285,9 @@ def test_full_size_conv_adjoint_identities(cin, cout, dims, n, ups):
         xd = torch.zeros_like(x[:1])
         xd[0, 0, 2, 2, 2] = 1.0
         yd = B.conv3d_k3_fwd(xd, w, None, 1)
-        assert torch.equal(yd[0, :, 1:4, 1:4, 1:4].cpu(), w[:, 0].flip(1, 2, 3).cpu())
+        # (to fp32 rounding: the Winograd kernels reconstruct each tap from sums of transformed taps)
+        got, want = yd[0, :, 1:4, 1:4, 1:4].cpu(), w[:, 0].flip(1, 2, 3).cpu()
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
 
 
 def test_full_size_bn_tail_properties():

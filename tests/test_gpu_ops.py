@@ -53,7 +53,7 @@ def rnd(gen, *shape, scale=1.0):
     return torch.randn(*shape, generator=gen) * scale
 
 
-# (Cin, Cout, dims, N, ups, path) -- path 0 = automatic dispatch, 1 = generic kernels
+# (Cin, Cout, dims, N, ups, path) -- path 0 = automatic dispatch, 1 = generic kernels, 3 = Winograd
 CONV_CASES = [
     (1, 4, (6, 7, 5), 1, 1, 0), (4, 4, (6, 7, 5), 3, 1, 0), (4, 8, (8, 12, 8), 1, 1, 0),
     (8, 4, (8, 12, 8), 3, 1, 0), (4, 1, (6, 7, 5), 3, 1, 0), (3, 5, (5, 4, 3), 2, 1, 0),
@@ -75,6 +75,10 @@ CONV_CASES = [
     # widths 10 / 20 (the two deepest levels of an 80x96x80 input): 10-wide bricks in 3-wave blocks
     (8, 64, (10, 24, 20), 1, 1, 0), (16, 64, (10, 24, 20), 1, 2, 0), (8, 128, (5, 12, 10), 2, 1, 0),
     (64, 64, (10, 12, 10), 1, 1, 0), (8, 64, (4, 6, 10), 1, 2, 0),
+    # Winograd F(2,3)-along-W kernels (path 3; falls back to the direct kernels where unsupported)
+    (8, 64, (8, 12, 8), 1, 1, 3), (64, 64, (5, 7, 9), 1, 1, 3), (64, 128, (8, 8, 16), 2, 1, 3),
+    (64, 64, (8, 12, 8), 2, 2, 3), (16, 64, (10, 24, 20), 1, 1, 3), (128, 64, (4, 8, 8), 1, 2, 3),
+    (72, 64, (4, 6, 10), 1, 1, 3), (64, 64, (16, 16, 16), 1, 1, 3),
     # the same wide shapes through the generic kernels (cross-check of the dispatcher)
     (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
 ]

@@ -27,8 +27,10 @@ def main():
     ap.add_argument("--ops", nargs="*", default=["fwd", "dgrad", "wgrad"])
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--path", type=int, default=0, help="siv_set_conv_path value (3 = Winograd)")
     a = ap.parse_args()
     B = sb.get_backend()
+    B.set_conv_path(a.path)
     dev = torch.device("cuda")
     # bring the clocks up before the first measurement
     wx = torch.randn(4096, 4096, device=dev)
