@@ -61,7 +61,7 @@ static bool use_wino(int path, bool aligned, int N, int D, int H, int W, int Cin
     if (!aligned || !k3_fwd_wino_supported(Cin, Cout)) return false;
     if (path == 3) return true;
     if (path != 0) return false;
-    return g_auto_wino && (long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8) * (Cout / 64) >= 1024;
+    return g_auto_wino && (long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8) * (Cout / 64) >= 512;
 }
 
 }  // namespace siv
