@@ -15,7 +15,7 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-int conv_path() { return g_conv_path == 4 ? 2 : g_conv_path; }
+int conv_path() { return g_conv_path; }
 
 // conv_generic.hip
 int k3_fwd_generic_launch(const float*, const float*, const float*, float*, int, int, int, int, int,

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}")
 DST = os.path.join(ROOT, "profiles")
-DOM = "k3_fwd_mfma<4, 8, 8, 4, 1, 64, 1>"
+DOM = "k3_fwd_wino<1>"
 DOM_GRID = "4915200"          # 8 volumes x 80x96x80 / 256-voxel bricks x 256 threads
 ALGO_BYTES = 2 * 8 * 80 * 96 * 80 * 64 * 4 + 27 * 64 * 64 * 4     # read x + write y + weights
 ALGO_FLOP = 2.0 * 27 * 64 * 64 * 80 * 96 * 80 * 8
@@ -75,9 +75,12 @@ Produced by `tools/profile_round.sh` on one MI355X, summarised by `tools/summari
 | MFMA pipe busy | **{100 * sq["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles:.1f} %** of SIMD-cycles |
 | SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY / SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY | {sq["SQ_WAVE_CYCLES"]:.4g} / {sq["SQ_WAIT_INST_ANY"]:.4g} / {sq["SQ_WAIT_ANY"]:.4g} / {sq["SQ_ACTIVE_INST_ANY"]:.4g} |
 
-Reading: the kernel is matrix-pipe bound (MFMA busy ~ achieved/peak).  The fetch side re-reads the
-6x10x10-voxel halo of every 4x8x8 brick (2.34x the input) -- those re-reads are served by L2 / the
-Infinity Cache (the counter sits on the L2's fabric side and includes Infinity-Cache hits) and, at
+Reading: the kernel applies Winograd F(2,3) along W, so it issues 18/27 of the direct-convolution
+multiply-adds: the TFLOP/s above are ALGORITHMIC (direct-convolution) rates; the matrix pipe itself
+runs at 2/3 of them (MFMA busy ~ that / peak).  The fetch side re-reads the 6x10x10-voxel halo of
+every 4x8x8 brick (2.34x the input, each halo row read as four overlapping columns per output pair)
+-- those re-reads are served by L2 / the Infinity Cache (the counter sits on the L2's fabric side and
+includes Infinity-Cache hits) and, at
 {traffic / 1e9 / (avg_ms / 1e3) / 1e3:.2f} TB/s, are far from the HBM roof, so they do not bound the kernel.
 """)
     print("wrote profiles for", TAG, "avg_ms", avg_ms, "traffic GB", traffic / 1e9)
