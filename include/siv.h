@@ -55,6 +55,16 @@ int siv_set_conv_path(int path);
 int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bias, float* y,
                       int N, int D, int H, int W, int Cin, int Cout, int ups,
                       void* ws, size_t ws_bytes, siv_stream_t stream);
+/* The same convolution followed by siv_bn_stats of its output (training-mode nn.BatchNorm3d
+ * after nn.Conv3d, models/models.py:17-18,21-22,55-56,59-60; models/mymodel.py:56-57 etc.) in one
+ * call: where the kernel family allows it the statistics are accumulated in the convolution's
+ * epilogue and y is not read again.  mean / var / running_* / num_batches_tracked as in
+ * siv_bn_stats. */
+int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const float* bias, float* y,
+                              int N, int D, int H, int W, int Cin, int Cout, int ups,
+                              float* mean, float* var, float* running_mean, float* running_var,
+                              int64_t* num_batches_tracked, float momentum,
+                              void* ws, size_t ws_bytes, siv_stream_t stream);
 /* Gradient w.r.t. the (non-upsampled) input of the same convolution: autograd of
  * nn.Conv3d.  dx is [N][D][H][W][Cin]; dy is [N][D][H][W][Cout]. */
 int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx,

@@ -91,13 +91,58 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
     const double ms = s1 / (double)M;
     double v = s2 / (double)M - ms * ms;
     if (v < 0.0) v = 0.0;
-    const double mu = (double)y[c] + ms;
+    const double mu = (y ? (double)y[c] : 0.0) + ms;
     mean[c] = (float)mu;
     var[c] = (float)v;
     if (rmean) {
         const double unb = (M > 1) ? v * ((double)M / (double)(M - 1)) : v;
         rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mu);
         rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+    }
+}
+
+// Same result for C % 4 == 0 with many partial rows: one 256-thread block per channel quad, each
+// thread sums the float4 of every 256th row in double, then a fixed-order block reduction.
+__global__ __launch_bounds__(256) void bn_stats_finalize_q(const float* __restrict__ y,
+                                                           const float* __restrict__ part, int nblk,
+                                                           long M, int C, float* __restrict__ mean,
+                                                           float* __restrict__ var,
+                                                           float* __restrict__ rmean,
+                                                           float* __restrict__ rvar,
+                                                           int64_t* __restrict__ nbt, float momentum) {
+    __shared__ double sh[4][8];
+    const int q = blockIdx.x;
+    if (q == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    double a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        const float4 p1 = *reinterpret_cast<const float4*>(part + ((long)b * 2 + 0) * C + 4 * q);
+        const float4 p2 = *reinterpret_cast<const float4*>(part + ((long)b * 2 + 1) * C + 4 * q);
+        a[0] += (double)p1.x; a[1] += (double)p1.y; a[2] += (double)p1.z; a[3] += (double)p1.w;
+        a[4] += (double)p2.x; a[5] += (double)p2.y; a[6] += (double)p2.z; a[7] += (double)p2.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = wave_sum_d(a[j]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sh[threadIdx.x >> 6][j] = a[j];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int j = threadIdx.x, c = 4 * q + j;
+        const double s1 = (sh[0][j] + sh[1][j]) + (sh[2][j] + sh[3][j]);
+        const double s2 = (sh[0][4 + j] + sh[1][4 + j]) + (sh[2][4 + j] + sh[3][4 + j]);
+        const double ms = s1 / (double)M;
+        double v = s2 / (double)M - ms * ms;
+        if (v < 0.0) v = 0.0;
+        const double mu = (y ? (double)y[c] : 0.0) + ms;
+        mean[c] = (float)mu;
+        var[c] = (float)v;
+        if (rmean) {
+            const double unb = (M > 1) ? v * ((double)M / (double)(M - 1)) : v;
+            rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mu);
+            rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+        }
     }
 }
 
@@ -626,6 +671,23 @@ extern "C" int siv_bn_stats(const float* y, long M, int C, float* mean, float* v
     SIV_CHECK_LAUNCH("bn_stats(finalize)");
     return SIV_OK;
 }
+
+namespace siv {
+// Finish batch statistics from per-block partial sums [nblk][2][C] of (value - shift[c]); shift may be
+// NULL (zero).  Used by the convolution that emits those sums from its epilogue.
+int bn_finalize_launch(const float* shift, const float* part, int nblk, long M, int C, float* mean,
+                       float* var, float* running_mean, float* running_var, int64_t* nbt,
+                       float momentum, hipStream_t s) {
+    if (C % 4 == 0 && nblk >= 512 && (((uintptr_t)part) & 15) == 0)
+        bn_stats_finalize_q<<<C / 4, 256, 0, s>>>(shift, part, nblk, M, C, mean, var, running_mean,
+                                                  running_var, nbt, momentum);
+    else
+        bn_stats_finalize<<<(C + 3) / 4, 256, 0, s>>>(shift, part, nblk, M, C, mean, var, running_mean,
+                                                          running_var, nbt, momentum);
+    SIV_CHECK_LAUNCH("bn_stats(finalize)");
+    return SIV_OK;
+}
+}  // namespace siv
 
 extern "C" int siv_bn_act_fwd(const float* y, const float* mean, const float* var,
                               const float* gamma, const float* beta, const float* residual,

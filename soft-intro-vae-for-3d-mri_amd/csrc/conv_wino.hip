@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256, 2) void k3_fwd_wino(const float* __restrict__ 
                                                       const float* __restrict__ wp,
                                                       const float* __restrict__ bias,
                                                       float* __restrict__ y, int N, int D, int H, int W,
-                                                      int Cin, int Cout, int nbd, int nbh, int nbw) {
+                                                      int Cin, int Cout, int nbd, int nbh, int nbw,
+                                                      float* __restrict__ stat_part) {
     using C = WinoCfg<UPS>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -163,12 +164,17 @@ __global__ __launch_bounds__(256, 2) void k3_fwd_wino(const float* __restrict__ 
     }
 
     // output transform + store: per row tile and output of the pair, transpose the 32x32 result
-    // through this wave's slice of LDS and write 16-byte channel runs
+    // through this wave's slice of LDS and write 16-byte channel runs.  When stat_part is given the
+    // block also emits, per output channel, the sum and the sum of squares of its (bias-free) outputs:
+    // the BatchNorm that follows gets its batch statistics without re-reading the tensor.
     float* tile = lds + wave * C::EPI_FLOATS;
     const int cq = lane & 7;
     const int co = co0 + wn * 32 + 4 * cq;
     float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias && co < Cout) bq = *reinterpret_cast<const float4*>(bias + co);
+    const int orig_b = blockIdx.x;
+    const bool full = z0 + C::BD <= D && y0 + C::BH <= H && x0 + C::BW <= W;   // no padded voxels
+    float s1 = 0.f, s2 = 0.f;     // this lane's column (channel co0 + wn*32 + li), its 16 rows per tile
 #pragma unroll
     for (int a = 0; a < C::AM; ++a) {
 #pragma unroll
@@ -178,7 +184,21 @@ __global__ __launch_bounds__(256, 2) void k3_fwd_wino(const float* __restrict__ 
             for (int r = 0; r < 16; ++r) {
                 const float v = half == 0 ? (acc[0][a][r] + acc[1][a][r]) + acc[2][a][r]
                                           : (acc[1][a][r] - acc[2][a][r]) - acc[3][a][r];
-                tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * C::EPI_STRIDE + li] = v;
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                tile[row * C::EPI_STRIDE + li] = v;
+                if (stat_part) {
+                    bool in = full;
+                    if (!full) {
+                        const int m = (wm * C::AM + a) * 32 + row;
+                        const int gz = z0 + m / (C::BH * C::PW), gy = y0 + (m / C::PW) % C::BH;
+                        const int gx = x0 + 2 * (m % C::PW) + half;
+                        in = gz < D && gy < H && gx < W;
+                    }
+                    if (in) {
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -192,6 +212,22 @@ __global__ __launch_bounds__(256, 2) void k3_fwd_wino(const float* __restrict__ 
                 if (gz < D && gy < H && gx < W && co < Cout)
                     *reinterpret_cast<float4*>(y + ((((long)n * D + gz) * H + gy) * W + gx) * Cout + co) = v;
             }
+        }
+    }
+    if (stat_part) {
+        s1 += __shfl_xor(s1, 32, 64);      // the two lane halves hold the same column
+        s2 += __shfl_xor(s2, 32, 64);
+        __syncthreads();
+        float* red = lds;                  // [2 (wm)][2 (sum, sumsq)][64 co]
+        if (lh == 0) {
+            red[(wm * 2 + 0) * 64 + wn * 32 + li] = s1;
+            red[(wm * 2 + 1) * 64 + wn * 32 + li] = s2;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int k = tid >> 6, c = tid & 63;
+            if (co0 + c < Cout)
+                stat_part[((long)orig_b * 2 + k) * Cout + co0 + c] = red[k * 64 + c] + red[(2 + k) * 64 + c];
         }
     }
 }
@@ -233,9 +269,15 @@ size_t k3_fwd_wino_ws_bytes(int Cin, int Cout) {
     return ((size_t)((Cout + 63) / 64) * ((Cin + 7) / 8) * 36 * 512 + 1024) * sizeof(float);
 }
 
+// stat_part (optional): receives [bricks][2][Cout] per-brick sums / sums of squares of the bias-free
+// output; *stat_blocks receives the number of bricks.  It must not overlap the first
+// k3_fwd_wino_ws_bytes() bytes of ws.
+long k3_fwd_wino_bricks(int N, int D, int H, int W) {
+    return (long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8);
+}
 int k3_fwd_wino_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H,
                        int W, int Cin, int Cout, int ups, int flip, void* ws, size_t ws_bytes,
-                       hipStream_t s) {
+                       hipStream_t s, float* stat_part) {
     SIV_CHECK_WS(k3_fwd_wino_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(winograd)");
     float* wp = (float*)ws;
     const long total = (long)((Cout + 63) / 64) * ((Cin + 7) / 8) * 36 * 512;
@@ -251,9 +293,10 @@ int k3_fwd_wino_launch(const float* x, const float* w, const float* bias, float*
     }
     const dim3 grid((unsigned)nblk, (unsigned)(Cout / 64));
     if (ups == 1)
-        k3_fwd_wino<1><<<grid, 256, WinoCfg<1>::LDS_BYTES, s>>>(x, wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
+        k3_fwd_wino<1><<<grid, 256, WinoCfg<1>::LDS_BYTES, s>>>(x, wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part);
     else
-        k3_fwd_wino<2><<<grid, 256, WinoCfg<2>::LDS_BYTES, s>>>(x, wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
+        k3_fwd_wino<2><<<grid, 256, WinoCfg<2>::LDS_BYTES, s>>>(x, wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw,
+                                                               stat_part);
     SIV_CHECK_LAUNCH("conv3d_k3(winograd)");
     return SIV_OK;
 }

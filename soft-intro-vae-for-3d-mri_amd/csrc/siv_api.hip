@@ -35,7 +35,12 @@ int k3_wgrad_mfma_launch(const float*, const float*, float*, int, int, int, int,
 // conv_wino.hip
 bool k3_fwd_wino_supported(int Cin, int Cout);
 int k3_fwd_wino_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int,
-                       int, int, void*, size_t, hipStream_t);
+                       int, int, void*, size_t, hipStream_t, float* stat_part);
+long k3_fwd_wino_bricks(int N, int D, int H, int W);
+size_t k3_fwd_wino_ws_bytes(int Cin, int Cout);
+// bn_act.hip
+int bn_finalize_launch(const float*, const float*, int, long, int, float*, float*, float*, float*,
+                       int64_t*, float, hipStream_t);
 // conv_thin.hip
 bool k3_thin_supported(int Cin, int Cout);
 int k3_thin_fwd_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int,
@@ -89,12 +94,43 @@ extern "C" int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bi
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
         return k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s);
     if (use_wino(path, al, N, D, H, W, Cin, Cout))
-        return k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s);
+        return k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s, nullptr);
     if (path != 1 && al && k3_fwd_mfma_supported(Cin, Cout))
         return k3_fwd_mfma_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s);
     SIV_CHECK_ARG(path != 2, "conv3d_k3_fwd: no specialised kernel for Cin=%d Cout=%d ups=%d", Cin,
                   Cout, ups);
     return k3_fwd_generic_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, s);
+}
+
+extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const float* bias, float* y,
+                                         int N, int D, int H, int W, int Cin, int Cout, int ups,
+                                         float* mean, float* var, float* running_mean,
+                                         float* running_var, int64_t* num_batches_tracked,
+                                         float momentum, void* ws, size_t ws_bytes,
+                                         siv_stream_t stream) {
+    SIV_CHECK_ARG(x && w && y && mean && var, "conv3d_k3_fwd_bnstats: null pointer");
+    SIV_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr),
+                  "conv3d_k3_fwd_bnstats: running_mean and running_var must both be given or both be NULL");
+    int rc = check_conv_shape("conv3d_k3_fwd_bnstats", N, D, H, W, Cin, Cout, ups);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const long M = (long)N * D * H * W;
+    const bool al = aligned16(x) && aligned16(w) && aligned16(y) && aligned16(ws);
+    if (use_wino(conv_path(), al, N, D, H, W, Cin, Cout)) {
+        // the convolution's epilogue emits per-brick sums of its bias-free output
+        const size_t wbytes = align256(k3_fwd_wino_ws_bytes(Cin, Cout));
+        const long nblk = k3_fwd_wino_bricks(N, D, H, W);
+        SIV_CHECK_WS(wbytes + (size_t)nblk * 2 * Cout * sizeof(float), ws_bytes, "conv3d_k3_fwd_bnstats");
+        float* part = (float*)((char*)ws + wbytes);
+        rc = k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s, part);
+        if (rc) return rc;
+        return bn_finalize_launch(bias, part, (int)nblk, M, Cout, mean, var, running_mean, running_var,
+                                  num_batches_tracked, momentum, s);
+    }
+    rc = siv_conv3d_k3_fwd(x, w, bias, y, N, D, H, W, Cin, Cout, ups, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return siv_bn_stats(y, M, Cout, mean, var, running_mean, running_var, num_batches_tracked, momentum, ws,
+                        ws_bytes, stream);
 }
 
 extern "C" int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx, int N, int D, int H,
@@ -110,7 +146,7 @@ extern "C" int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx, i
     if (path != 1 && al && k3_thin_supported(Cout, Cin))
         return k3_thin_fwd_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, s);
     if (use_wino(path, al, N, D, H, W, Cout, Cin))
-        return k3_fwd_wino_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s);
+        return k3_fwd_wino_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s, nullptr);
     if (path != 1 && al && k3_fwd_mfma_supported(Cout, Cin))
         return k3_fwd_mfma_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s);
     SIV_CHECK_ARG(path != 2, "conv3d_k3_dgrad: no specialised kernel for Cin=%d Cout=%d", Cin, Cout);

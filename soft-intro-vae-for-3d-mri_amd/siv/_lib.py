@@ -14,6 +14,7 @@ _i, _l, _fl, _sz, _u64 = C.c_int, C.c_long, C.c_float, C.c_size_t, C.c_uint64
 SIGNATURES = {
     "siv_set_conv_path": [_i],
     "siv_conv3d_k3_fwd": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
+    "siv_conv3d_k3_fwd_bnstats": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _fl, _f, _sz, _f],
     "siv_conv3d_k3_dgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_conv3d_k3_wgrad": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_upsample2_bwd": [_f, _f, _i, _i, _i, _i, _i, _f],

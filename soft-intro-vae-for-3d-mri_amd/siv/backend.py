@@ -93,6 +93,24 @@ class HipBackend:
                                               ws, wsb, self._stream(x)), "siv_conv3d_k3_fwd")
         return y
 
+    def conv3d_k3_fwd_stats(self, x, w, bias, ups, running_mean, running_var, nbt, momentum: float):
+        """Convolution + training-mode BatchNorm statistics of its output: (y, mean, biased var)."""
+        self._check_dev(x, w, bias, running_mean, running_var, nbt)
+        x, w = cl(x), cl(w)
+        N, Cin, Di, Hi, Wi = x.shape
+        Cout = w.shape[0]
+        assert w.shape[1] == Cin and tuple(w.shape[2:]) == (3, 3, 3), (tuple(w.shape), Cin)
+        D, H, W = Di * ups, Hi * ups, Wi * ups
+        y = empty_cl((N, Cout, D, H, W), x)
+        mean = torch.empty(Cout, device=x.device, dtype=torch.float32)
+        var = torch.empty(Cout, device=x.device, dtype=torch.float32)
+        ws, wsb = self._workspace(x)
+        _lib.check(self.lib.siv_conv3d_k3_fwd_bnstats(_p(x), _p(w), _p(bias), _p(y), N, D, H, W, Cin, Cout, ups,
+                                                      _p(mean), _p(var), _p(running_mean), _p(running_var),
+                                                      _p(nbt), float(momentum), ws, wsb, self._stream(x)),
+                   "siv_conv3d_k3_fwd_bnstats")
+        return y, mean, var
+
     def conv3d_k3_dgrad(self, dy, w, ups: int = 1):
         self._check_dev(dy, w)
         dy, w = cl(dy), cl(w)

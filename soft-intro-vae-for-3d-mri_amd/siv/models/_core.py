@@ -85,10 +85,8 @@ class BuildingBlock(_ResBlockBase):
     def forward(self, x):
         c1, b1, _, _, c2, b2 = self.block
         s = self.variant.slope
-        h = ops.conv3d_k3(x, c1.weight, c1.bias)
-        h = ops.bn_act(h, b1, s, pool=self.stride, train=self.training)
-        h = ops.conv3d_k3(h, c2.weight, c2.bias)
-        return ops.bn_act(h, b2, s, residual=self._res(x), train=self.training)
+        h = ops.conv_bn_act(x, c1, b1, s, pool=self.stride, train=self.training)
+        return ops.conv_bn_act(h, c2, b2, s, residual=self._res(x), train=self.training)
 
 
 class UpsampleBuildingkBlock(_ResBlockBase):
@@ -118,10 +116,8 @@ class UpsampleBuildingkBlock(_ResBlockBase):
         s = self.variant.slope
         if self.stride not in (1, 2):
             raise ValueError(f"only stride 1 or 2 is supported (got {self.stride})")
-        h = ops.conv3d_k3(x, c1.weight, c1.bias)
-        h = ops.bn_act(h, b1, s, train=self.training)
-        h = ops.conv3d_k3(h, c2.weight, c2.bias, ups=self.stride)
-        return ops.bn_act(h, b2, s, residual=self._res(x), train=self.training)
+        h = ops.conv_bn_act(x, c1, b1, s, train=self.training)
+        return ops.conv_bn_act(h, c2, b2, s, ups=self.stride, residual=self._res(x), train=self.training)
 
 
 class ResNetEncoder(nn.Module):
@@ -149,9 +145,8 @@ class ResNetEncoder(nn.Module):
     def features(self, x):
         v = self.variant
         conv, bn = self.blocks[0][0], self.blocks[0][1]
-        h = ops.conv3d_k3(x, conv.weight, conv.bias)
-        keep = _keep(h.shape, v.p_enc_stem, self.training, h.device)
-        h = ops.bn_act(h, bn, v.slope, keep=keep, p=v.p_enc_stem, train=self.training)
+        keep = _keep((x.shape[0], conv.out_channels) + tuple(x.shape[2:]), v.p_enc_stem, self.training, x.device)
+        h = ops.conv_bn_act(x, conv, bn, v.slope, keep=keep, p=v.p_enc_stem, train=self.training)
         for blk in list(self.blocks)[1:]:
             h = blk[0](h)
         return h

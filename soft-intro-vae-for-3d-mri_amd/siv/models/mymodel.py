@@ -34,8 +34,7 @@ def _cbl(cin, cout):
 
 
 def _conv_bn_act(x, conv, bn, train, pool=1, ups=1, residual=None):
-    h = ops.conv3d_k3(x, conv.weight, conv.bias, ups=ups)
-    return ops.bn_act(h, bn, SLOPE, pool=pool, residual=residual, train=train)
+    return ops.conv_bn_act(x, conv, bn, SLOPE, ups=ups, pool=pool, residual=residual, train=train)
 
 
 class BaseEncoder(nn.Module):

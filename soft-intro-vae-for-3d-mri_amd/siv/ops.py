@@ -38,14 +38,21 @@ def _wgrad_beside_dgrad(B, dy, wgrad_fn, dgrad_fn):
 
 class _Conv3dK3(Function):
     @staticmethod
-    def forward(ctx, x, w, bias, ups):
+    def forward(ctx, x, w, bias, ups, bn=None):
         ctx.save_for_backward(x, w)
         ctx.ups = ups
         ctx.has_bias = bias is not None
-        return get_backend().conv3d_k3_fwd(x, w, bias, ups)
+        if bn is None:
+            return get_backend().conv3d_k3_fwd(x, w, bias, ups)
+        # training-mode BatchNorm follows: its batch statistics come out of the same call
+        y, mean, var = get_backend().conv3d_k3_fwd_stats(
+            x, w, bias, ups, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+            BN_MOMENTUM if bn.momentum is None else bn.momentum)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         x, w = ctx.saved_tensors
         B = get_backend()
         dx = dw = db = None
@@ -60,12 +67,12 @@ class _Conv3dK3(Function):
             dw, db = B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b)
         if not ctx.needs_input_grad[1]:
             dw = None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def conv3d_k3(x, w, bias=None, ups: int = 1):
     """nn.Conv3d(k=3, s=1, p=1), optionally fused with a preceding nearest x2 upsample."""
-    return _Conv3dK3.apply(x, w, bias, ups)
+    return _Conv3dK3.apply(x, w, bias, ups, None)
 
 
 class _Conv1x1(Function):
@@ -143,9 +150,11 @@ def add_act(a, b, slope: float):
 
 class _BnAct(Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, res, keep, bn, p, slope, pool, train):
+    def forward(ctx, y, gamma, beta, res, keep, bn, p, slope, pool, train, stats=None):
         B = get_backend()
-        if train:
+        if train and stats is not None:
+            mean, var = stats          # already computed (and the running statistics updated)
+        elif train:
             mean, var = B.bn_stats(y, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                    BN_MOMENTUM if bn.momentum is None else bn.momentum)
         else:
@@ -169,16 +178,28 @@ class _BnAct(Function):
         if not ctx.needs_input_grad[0]:
             dy = None
         return (dy, dg if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None,
-                dres, None, None, None, None, None, None)
+                dres, None, None, None, None, None, None, None)
 
 
 def bn_act(y, bn, slope: float, pool: int = 1, residual=None, keep=None, p: float = 0.0,
-           train: bool = True):
+           train: bool = True, stats=None):
     """BatchNorm3d (parameters/buffers of module ``bn``) -> [+residual] -> LeakyReLU(slope)
-    -> AvgPool3d(pool) -> dropout(keep, p) as one fused pass."""
+    -> AvgPool3d(pool) -> dropout(keep, p) as one fused pass.  ``stats`` = (mean, biased var) when
+    the producer of ``y`` already computed the batch statistics."""
     if pool not in (1, 2):
         raise ValueError(f"only stride/pool 1 or 2 is supported (got {pool})")
-    return _BnAct.apply(y, bn.weight, bn.bias, residual, keep, bn, p, slope, pool, train)
+    return _BnAct.apply(y, bn.weight, bn.bias, residual, keep, bn, p, slope, pool, train, stats)
+
+
+def conv_bn_act(x, conv, bn, slope: float, ups: int = 1, pool: int = 1, residual=None, keep=None,
+                p: float = 0.0, train: bool = True):
+    """conv3d_k3 (parameters of module ``conv``) followed by ``bn_act``.  In training mode the
+    convolution call also produces the BatchNorm batch statistics."""
+    if train:
+        y, mean, var = _Conv3dK3.apply(x, conv.weight, conv.bias, ups, bn)
+        return bn_act(y, bn, slope, pool, residual, keep, p, True, (mean, var))
+    y = _Conv3dK3.apply(x, conv.weight, conv.bias, ups, None)
+    return bn_act(y, bn, slope, pool, residual, keep, p, False)
 
 
 class _ActDropout(Function):

@@ -19,6 +19,11 @@ class CpuCheckerBackend:
     def conv3d_k3_fwd(self, x, w, bias, ups=1):
         return O.conv3d_k3(x, w, bias, ups)
 
+    def conv3d_k3_fwd_stats(self, x, w, bias, ups, running_mean, running_var, nbt, momentum):
+        y = O.conv3d_k3(x, w, bias, ups)
+        mean, var = self.bn_stats(y, running_mean, running_var, nbt, momentum)
+        return y, mean, var
+
     def conv3d_k3_dgrad(self, dy, w, ups=1):
         N, Cout, D, H, W = dy.shape
         dx = nngrad.conv3d_input((N, w.shape[1], D, H, W), w, dy, stride=1, padding=1)

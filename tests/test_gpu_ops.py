@@ -380,3 +380,35 @@ def test_add_act(B, shape):
     d = B.add_act_bwd(dev(dout), dev(a), dev(b), 0.2)
     s = a + b
     check(d, dout * torch.where(s > 0, torch.ones_like(s), torch.full_like(s, 0.2)), "add_act bwd", max_outliers=2)
+
+
+@pytest.mark.parametrize("cin,cout,dims,n,ups,path,use_bias", [
+    (64, 64, (8, 12, 8), 2, 1, 3, False), (8, 64, (5, 7, 9), 3, 1, 3, True), (64, 128, (8, 8, 16), 1, 2, 3, True),
+    (16, 64, (10, 24, 20), 1, 1, 3, False),            # statistics from the Winograd epilogue
+    (4, 8, (6, 7, 5), 2, 1, 0, True), (1, 8, (8, 12, 8), 2, 1, 0, True), (64, 64, (10, 12, 10), 1, 1, 0, False),
+])
+def test_conv_fwd_with_bn_statistics(B, cin, cout, dims, n, ups, path, use_bias):
+    """siv_conv3d_k3_fwd_bnstats == convolution followed by siv_bn_stats (incl. running statistics),
+    both where the convolution kernel emits the sums itself and where it falls back."""
+    gen = torch.Generator().manual_seed(cin + cout + dims[2] + ups)
+    D, H, W = dims
+    x = rnd(gen, n, cin, D // ups, H // ups, W // ups) + 0.3
+    w = rnd(gen, cout, cin, 3, 3, 3, scale=(2.0 / (27 * cin)) ** 0.5)
+    b = rnd(gen, cout) * 3 if use_bias else None          # a bias far from zero: the sums are bias-free
+    rm0, rv0 = rnd(gen, cout), torch.rand(cout, generator=gen) + 0.5
+    rm, rv, nbt = dev(rm0.clone()), dev(rv0.clone()), torch.tensor(4, device="cuda")
+    B.set_conv_path(path)
+    try:
+        y, mean, var = B.conv3d_k3_fwd_stats(dev(x), dev(w), dev(b), ups, rm, rv, nbt, 0.1)
+    finally:
+        B.set_conv_path(0)
+    yr = O.conv3d_k3(x, w, b, ups)
+    check(y, yr, "conv output")
+    m = yr.numel() // cout
+    mr = yr.double().mean(dim=(0, 2, 3, 4))
+    vr = yr.double().var(dim=(0, 2, 3, 4), unbiased=False)
+    check(mean, mr.float(), "mean")
+    check(var, vr.float(), "biased variance")
+    check(rm, (0.9 * rm0.double() + 0.1 * mr).float(), "running mean")
+    check(rv, (0.9 * rv0.double() + 0.1 * vr * m / (m - 1)).float(), "running var")
+    assert int(nbt) == 5
