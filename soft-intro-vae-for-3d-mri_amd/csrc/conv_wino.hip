@@ -15,6 +15,13 @@
 // the weight transform when the weights are packed, the output transform on the accumulators.
 #include "siv_common.h"
 
+// SIV_WEXP: timing-only ablation mask used by tools/ubench (never set in the library build):
+// 1 = no weight-fragment loads, 2 = no LDS fragment reads, 4 = no halo loads, 8 = no output stores,
+// 16 = no input transform / LDS halo writes.
+#ifndef SIV_WEXP
+#define SIV_WEXP 0
+#endif
+
 namespace siv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -37,7 +44,6 @@ struct WinoCfg {
     static constexpr int EPI_STRIDE = 40, EPI_FLOATS = 32 * EPI_STRIDE;
     static constexpr int LDS_FLOATS = V_FLOATS > NW * EPI_FLOATS ? V_FLOATS : NW * EPI_FLOATS;
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
-    static constexpr int NH = (HP * 2 + NTHR - 1) / NTHR; // staging items per thread: 2
 };
 
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -91,41 +97,38 @@ __global__ __launch_bounds__(256, 2) void k3_fwd_wino(const float* __restrict__ 
     float4 bn1 = *reinterpret_cast<const float4*>(wlane);
     float4 bn2 = *reinterpret_cast<const float4*>(wlane + C::SLICE);
 
-    // halo staging: item = (halo row, pair, channel half); four raw inputs d0..d3 per item
-    float4 hreg[C::NH][4];
+    // halo staging: thread = (halo row, half of the row, channel half).  It loads the six raw columns
+    // its two output pairs depend on (pairs 2h, 2h+1 use columns 4h..4h+3 and 4h+2..4h+5) and writes
+    // their 2 x 4 transformed values: 6 loads for 8 LDS writes, 240 of the 256 threads busy.
+    static_assert(C::PW == 4 && C::HD * C::HH * 4 <= C::NTHR, "staging map assumes 4 pairs per row");
+    const int s_q = tid & 1, s_half = (tid >> 1) & 1, s_row = tid >> 2;
+    const bool s_on = s_row < C::HD * C::HH;
+    float4 hreg[6];
     auto load_halo = [&](int c0) {
+        const int hy = s_row % C::HH, hz = s_row / C::HH;
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1;
+        const bool rowok = s_on && c0 + 4 * s_q < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H;
+        const long rowbase = (((long)n * Di + gz / UPS) * Hi + gy / UPS) * Wi;
 #pragma unroll
-        for (int i = 0; i < C::NH; ++i) {
-            const int idx = tid + C::NTHR * i;
-            const int q = idx & 1, it = idx >> 1;
-            const int px = it % C::PW, hrow = it / C::PW;
-            const int hy = hrow % C::HH, hz = hrow / C::HH;
-            const int gz = z0 + hz - 1, gy = y0 + hy - 1;
-            const bool rowok = it < C::HP && c0 + 4 * q < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H;
-            const long rowbase = (((long)n * Di + gz / UPS) * Hi + gy / UPS) * Wi;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gx = x0 + 2 * px - 1 + j;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rowok && gx >= 0 && gx < W)
-                    v = *reinterpret_cast<const float4*>(x + (rowbase + gx / UPS) * Cin + c0 + 4 * q);
-                hreg[i][j] = v;
-            }
+        for (int j = 0; j < 6; ++j) {
+            const int gx = x0 + 4 * s_half - 1 + j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(SIV_WEXP & 4) && rowok && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4*>(x + (rowbase + gx / UPS) * Cin + c0 + 4 * s_q);
+            hreg[j] = v;
         }
     };
     load_halo(0);
     for (int cc = 0; cc < nchunk; ++cc) {
         __syncthreads();  // previous chunk's MFMAs are done with V
+        if (s_on && (!(SIV_WEXP & 16) || hreg[0].x == 123.f)) {
 #pragma unroll
-        for (int i = 0; i < C::NH; ++i) {
-            const int idx = tid + C::NTHR * i;
-            const int q = idx & 1, it = idx >> 1;
-            if (it < C::HP) {
-                float* dst = lds + it * C::CKP + 4 * q;
-                *reinterpret_cast<float4*>(dst) = f4sub(hreg[i][0], hreg[i][2]);
-                *reinterpret_cast<float4*>(dst + C::PLANE) = f4add(hreg[i][1], hreg[i][2]);
-                *reinterpret_cast<float4*>(dst + 2 * C::PLANE) = f4sub(hreg[i][2], hreg[i][1]);
-                *reinterpret_cast<float4*>(dst + 3 * C::PLANE) = f4sub(hreg[i][1], hreg[i][3]);
+            for (int pp = 0; pp < 2; ++pp) {
+                float* dst = lds + (s_row * C::PW + 2 * s_half + pp) * C::CKP + 4 * s_q;
+                *reinterpret_cast<float4*>(dst) = f4sub(hreg[2 * pp], hreg[2 * pp + 2]);
+                *reinterpret_cast<float4*>(dst + C::PLANE) = f4add(hreg[2 * pp + 1], hreg[2 * pp + 2]);
+                *reinterpret_cast<float4*>(dst + 2 * C::PLANE) = f4sub(hreg[2 * pp + 2], hreg[2 * pp + 1]);
+                *reinterpret_cast<float4*>(dst + 3 * C::PLANE) = f4sub(hreg[2 * pp + 1], hreg[2 * pp + 3]);
             }
         }
         __syncthreads();
@@ -142,13 +145,17 @@ __global__ __launch_bounds__(256, 2) void k3_fwd_wino(const float* __restrict__ 
             bn1 = bn2;
 #pragma unroll
             for (int a = 0; a < C::AM; ++a) av[a] = anext[a];
-            bn2 = *reinterpret_cast<const float4*>(wc + (t + 2) * C::SLICE);
+            if (!(SIV_WEXP & 1)) bn2 = *reinterpret_cast<const float4*>(wc + (t + 2) * C::SLICE);
             if (t + 1 < C::TAPS) {
                 const int t1 = t + 1;
                 const int tapoff = (t1 & 3) * C::PLANE + (((t1 / 12) * C::HH + (t1 / 4) % 3) * C::PW) * C::CKP;
 #pragma unroll
-                for (int a = 0; a < C::AM; ++a)
-                    anext[a] = *reinterpret_cast<const float4*>(lds + aoff[a] + tapoff);
+                for (int a = 0; a < C::AM; ++a) {
+                    if (SIV_WEXP & 2)
+                        asm volatile("" : "+v"(anext[a].x), "+v"(anext[a].y), "+v"(anext[a].z), "+v"(anext[a].w));
+                    else
+                        anext[a] = *reinterpret_cast<const float4*>(lds + aoff[a] + tapoff);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #define SIV_WSTEP(F)                                                                        \
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void k3_fwd_wino(const float* __restrict__ 
                 const int gx = x0 + 2 * (m % C::PW) + half;
                 float4 v = *reinterpret_cast<const float4*>(tile + row * C::EPI_STRIDE + 4 * cq);
                 v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
-                if (gz < D && gy < H && gx < W && co < Cout)
+                if (gz < D && gy < H && gx < W && co < Cout && (!(SIV_WEXP & 8) || v.x == 123.f))
                     *reinterpret_cast<float4*>(y + ((((long)n * D + gz) * H + gy) * W + gx) * Cout + co) = v;
             }
         }
