@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsiv.so")
+LIB_PATH = os.environ.get("SIV_LIB", os.path.join(_HERE, "libsiv.so"))   # SIV_LIB: A/B builds of the library
 
 _f = C.c_void_p      # device pointers travel as integers
 _i, _l, _fl, _sz, _u64 = C.c_int, C.c_long, C.c_float, C.c_size_t, C.c_uint64
