@@ -320,7 +320,10 @@ static FwdKind fwd_kind(int D, int H, int W, int Cout) {
     if (W == 10) return kW10b;
     return use_small_brick(D, H, W) ? kSmall : kBig;
 }
-static int fwd_tile(FwdKind k) { return (k == kN32 || k == kW10b) ? 32 : 64; }
+static int fwd_tile(FwdKind k, int Cout) {
+    if (k == kW10b) return Cout % 128 == 0 ? 128 : 32;
+    return k == kN32 ? 32 : 64;
+}
 size_t k3_fwd_mfma_ws_bytes(int Cin, int Cout) {   // upper bound over both tile widths
     return ((size_t)((Cout + 31) / 32) * ((Cin + 7) / 8) * 27 * 32 * 8 + 1024) * sizeof(float);
 }
@@ -333,7 +336,7 @@ int k3_fwd_mfma_launch(const float* x, const float* w, const float* bias, float*
     SIV_CHECK_WS(k3_fwd_mfma_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(mfma)");
     float* wp = (float*)ws;
     const FwdKind kind = fwd_kind(D, H, W, Cout);
-    const int NT = fwd_tile(kind);
+    const int NT = fwd_tile(kind, Cout);
     const long total = (long)((Cout + NT - 1) / NT) * ((Cin + 7) / 8) * 27 * NT * 8;
     long g = cdiv(total, 256);
     if (g > 4096) g = 4096;
@@ -344,7 +347,7 @@ int k3_fwd_mfma_launch(const float* x, const float* w, const float* bias, float*
               : launch_fwd<BD, BH, BW, WM, WN, NTT, 2>(x, wp, bias, y, N, D, H, W, Cin, Cout, s))
     switch (kind) {
         case kN32: return SIV_FWD(4, 8, 8, 4, 1, 32);
-        case kW10b: return SIV_FWD(2, 4, 10, 3, 1, 32);
+        case kW10b: return NT == 128 ? SIV_FWD(2, 4, 10, 1, 4, 128) : SIV_FWD(2, 4, 10, 3, 1, 32);
         case kSmall: return SIV_FWD(2, 4, 8, 2, 2, 64);
         default: return SIV_FWD(4, 8, 8, 4, 1, 64);
     }
