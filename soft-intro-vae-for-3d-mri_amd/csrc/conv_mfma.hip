@@ -502,9 +502,12 @@ __global__ __launch_bounds__(256, 2) void k3_wgrad_mfma(const float* __restrict_
 }
 
 // (A transposed-Winograd F(2,3) variant of this kernel -- 4 position sums per filter row instead of 3
-// taps, 12 accumulators per wave -- was measured: at 2 waves per SIMD it spills and loses its
-// register-prefetched staging (11.1 ms against 8.5 ms for 64->64@80x96x80), at 1 wave per SIMD it
-// gains 3 %.  Not kept.)
+// taps, 12 accumulators = 192 registers per wave -- was built and measured on 64->64@80x96x80, where
+// this kernel takes 8.5 ms: at 2 waves per SIMD it spills and loses its register-prefetched staging
+// (11.1 ms); at 1 wave per SIMD, with double-buffered LDS and software-pipelined operand reads, it
+// reaches 8.2-8.3 ms: a single wave cannot hide the ~600 VALU instructions of staging index arithmetic
+// per brick, and keeping that arithmetic in brick-invariant registers pushed the compiler into
+// scratch.  Not kept.)
 
 // dw[e] = (accumulate ? dw[e] : 0) + sum_s part[s][e], fixed order
 __global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ part, int nslab, long n,
