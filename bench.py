@@ -127,21 +127,26 @@ def main():
     # launch of the 64->64 conv at full resolution inside the timed region
     dom_events = []
     recording = {"on": False}
-    orig_fwd = B.conv3d_k3_fwd
 
-    def timed_fwd(x, w, bias, ups=1):
-        hit = (recording["on"] and ups == 1 and w.shape[0] == 64 and w.shape[1] == 64
-               and tuple(x.shape[2:]) == DIMS)
-        if not hit:
-            return orig_fwd(x, w, bias, ups)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        y = orig_fwd(x, w, bias, ups)
-        e1.record()
-        dom_events.append((e0, e1, x.shape[0]))
-        return y
+    def timed(orig):
+        def call(x, w, bias, ups=1, *rest):
+            hit = (recording["on"] and ups == 1 and w.shape[0] == 64 and w.shape[1] == 64
+                   and tuple(x.shape[2:]) == DIMS)
+            if not hit:
+                return orig(x, w, bias, ups, *rest)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(x, w, bias, ups, *rest)
+            e1.record()
+            dom_events.append((e0, e1, x.shape[0]))
+            return out
+        return call
 
-    B.conv3d_k3_fwd = timed_fwd
+    # the layer runs through conv3d_k3_fwd_stats in training mode (convolution + BatchNorm statistics
+    # in one C call: the event pair then also spans the weight-packing and the statistics-finalize
+    # launches, ~15 us of 5.8 ms) and through conv3d_k3_fwd otherwise
+    B.conv3d_k3_fwd = timed(B.conv3d_k3_fwd)
+    B.conv3d_k3_fwd_stats = timed(B.conv3d_k3_fwd_stats)
 
     def one_step(i):
         real = batches[i % n_batches]
