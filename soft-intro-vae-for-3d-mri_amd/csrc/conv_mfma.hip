@@ -119,20 +119,25 @@ __global__ __launch_bounds__(64 * WM * WN) void k3_fwd_mfma(const float* __restr
     // critical path of the block.
     constexpr int NH = (C::HV * 2 + C::NTHR - 1) / C::NTHR;
     float4 hreg[NH];
+    // chunk-invariant part of the addresses and their validity, computed once per block
+    long hoff[NH];
+    unsigned hmask = 0;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int idx = tid + C::NTHR * i;
+        const int hv = idx >> 1, q = idx & 1;
+        const int hx = hv % C::HW, hy = (hv / C::HW) % C::HH, hz = hv / (C::HW * C::HH);
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = hv < C::HV && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        hoff[i] = ok ? ((((long)n * Di + gz / UPS) * Hi + gy / UPS) * Wi + gx / UPS) * Cin + 4 * q : 0;
+        hmask |= (unsigned)ok << i;
+    }
     auto load_halo = [&](int c0) {
+        const bool chok = c0 + 4 * (tid & 1) < Cin;
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
-            const int idx = tid + C::NTHR * i;
-            const int hv = idx >> 1, q = idx & 1;
-            const int hx = hv % C::HW, hy = (hv / C::HW) % C::HH, hz = hv / (C::HW * C::HH);
-            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!(SIV_EXP & 4) && hv < C::HV && c0 + 4 * q < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H &&
-                gx >= 0 && gx < W) {
-                const long off =
-                    ((((long)n * Di + gz / UPS) * Hi + gy / UPS) * Wi + gx / UPS) * Cin + c0 + 4 * q;
-                v = *reinterpret_cast<const float4*>(x + off);
-            }
+            if (!(SIV_EXP & 4) && chok && ((hmask >> i) & 1)) v = *reinterpret_cast<const float4*>(x + hoff[i] + c0);
             hreg[i] = v;
         }
     };

@@ -18,6 +18,9 @@
 // SIV_WEXP: timing-only ablation mask used by tools/ubench (never set in the library build):
 // 1 = no weight-fragment loads, 2 = no LDS fragment reads, 4 = no halo loads, 8 = no output stores,
 // 16 = no input transform / LDS halo writes.
+#ifndef SIV_WPD
+#define SIV_WPD 6      // weight-fragment prefetch distance in taps (divides 36)
+#endif
 #ifndef SIV_WEXP
 #define SIV_WEXP 0
 #endif
@@ -94,8 +97,11 @@ __global__ __launch_bounds__(256, 2) void k3_fwd_wino(const float* __restrict__ 
     }
     // this lane's B fragment inside a packed [64 co][8 ci] slice
     const float* wlane = wp + (long)blockIdx.y * nchunk * C::TAPS * C::SLICE + (wn * 32 + li) * 8 + 4 * lh;
-    float4 bn1 = *reinterpret_cast<const float4*>(wlane);
-    float4 bn2 = *reinterpret_cast<const float4*>(wlane + C::SLICE);
+    // weight fragments are fetched PD taps ahead of their MFMAs (a ring of PD registers quads; PD
+    // divides the 36 taps so that the ring index is a compile-time constant)
+    constexpr int PD = SIV_WPD;
+    static_assert(C::TAPS % PD == 0, "ring index must not depend on the chunk");
+    float4 bring[PD];
 
     // halo staging: thread = (halo row, half of the row, channel half).  It loads the six raw columns
     // its two output pairs depend on (pairs 2h, 2h+1 use columns 4h..4h+3 and 4h+2..4h+5) and writes
@@ -104,23 +110,53 @@ __global__ __launch_bounds__(256, 2) void k3_fwd_wino(const float* __restrict__ 
     const int s_q = tid & 1, s_half = (tid >> 1) & 1, s_row = tid >> 2;
     const bool s_on = s_row < C::HD * C::HH;
     float4 hreg[6];
-    auto load_halo = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) hreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // chunk-invariant part of the six addresses (offsets from x of this thread's channel quad in
+    // chunk 0) and their validity, computed once: per chunk only an add and a select remain
+    long hoff[6];
+    unsigned hmask = 0;
+    {
         const int hy = s_row % C::HH, hz = s_row / C::HH;
         const int gz = z0 + hz - 1, gy = y0 + hy - 1;
-        const bool rowok = s_on && c0 + 4 * s_q < Cin && gz >= 0 && gz < D && gy >= 0 && gy < H;
-        const long rowbase = (((long)n * Di + gz / UPS) * Hi + gy / UPS) * Wi;
+        const bool rowok = s_on && gz >= 0 && gz < D && gy >= 0 && gy < H;
+        const long rowbase = (((long)n * Di + (rowok ? gz : 0) / UPS) * Hi + (rowok ? gy : 0) / UPS) * Wi;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int gx = x0 + 4 * s_half - 1 + j;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!(SIV_WEXP & 4) && rowok && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4*>(x + (rowbase + gx / UPS) * Cin + c0 + 4 * s_q);
-            hreg[j] = v;
+            const bool ok = rowok && gx >= 0 && gx < W;
+            hoff[j] = ok ? (rowbase + gx / UPS) * Cin + 4 * s_q : 0;
+            if (SIV_WEXP & 32) hoff[j] &= 0xFFFF;     // timing only: every halo comes from one 256 KB window
+            hmask |= (unsigned)ok << j;
         }
+    }
+    // The loads are unconditional (out-of-volume columns read voxel 0 and are zeroed when they are
+    // consumed): straight-line code lets the compiler wait for exactly these six loads at the top of
+    // the next chunk and leave the younger weight-fragment loads in flight.
+    auto load_halo = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (!(SIV_WEXP & 4)) hreg[j] = *reinterpret_cast<const float4*>(x + hoff[j] + c0);
     };
     load_halo(0);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) bring[i] = *reinterpret_cast<const float4*>(wlane + i * C::SLICE);
+    // Nothing can start before the first halo has arrived anyway.  Pinning the loaded values here (the
+    // empty asm statements make the compiler wait for each of them) costs nothing and leaves the loop
+    // with one known state on entry: inside it the compiler then counts, per wait, the loads that may
+    // stay in flight (loads return in order), instead of taking the worse of two orders and draining
+    // the weight-fragment pipeline at the top of every chunk.
+#define SIV_PIN(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
+#pragma unroll
+    for (int j = 0; j < 6; ++j) SIV_PIN(hreg[j]);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) SIV_PIN(bring[i]);
+#undef SIV_PIN
     for (int cc = 0; cc < nchunk; ++cc) {
         __syncthreads();  // previous chunk's MFMAs are done with V
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (!((hmask >> j) & 1)) hreg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (s_on && (!(SIV_WEXP & 16) || hreg[0].x == 123.f)) {
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
@@ -132,7 +168,10 @@ __global__ __launch_bounds__(256, 2) void k3_fwd_wino(const float* __restrict__ 
             }
         }
         __syncthreads();
-        if (cc + 1 < nchunk) load_halo((cc + 1) * C::CK);
+        // (the last chunk re-requests its own halo rather than branching around the loads: with one
+        // instruction stream the compiler can count exactly how many younger loads may stay in flight
+        // at each wait, instead of assuming the shorter of two paths)
+        load_halo((cc + 1 < nchunk ? cc + 1 : cc) * C::CK);
         const float* wc = wlane + (long)cc * C::TAPS * C::SLICE;
         float4 anext[C::AM];
 #pragma unroll
@@ -141,11 +180,10 @@ __global__ __launch_bounds__(256, 2) void k3_fwd_wino(const float* __restrict__ 
         for (int t = 0; t < C::TAPS; ++t) {
             const int pos = t & 3;
             float4 av[C::AM];
-            const float4 bv = bn1;
-            bn1 = bn2;
+            const float4 bv = bring[t % PD];
 #pragma unroll
             for (int a = 0; a < C::AM; ++a) av[a] = anext[a];
-            if (!(SIV_WEXP & 1)) bn2 = *reinterpret_cast<const float4*>(wc + (t + 2) * C::SLICE);
+            if (!(SIV_WEXP & 1)) bring[t % PD] = *reinterpret_cast<const float4*>(wc + (t + PD) * C::SLICE);
             if (t + 1 < C::TAPS) {
                 const int t1 = t + 1;
                 const int tapoff = (t1 & 3) * C::PLANE + (((t1 / 12) * C::HH + (t1 / 4) % 3) * C::PW) * C::CKP;
@@ -273,7 +311,7 @@ __global__ __launch_bounds__(256) void k3_pack_weights_wino(const float* __restr
 
 bool k3_fwd_wino_supported(int Cin, int Cout) { return Cin % 8 == 0 && Cout % 64 == 0; }
 size_t k3_fwd_wino_ws_bytes(int Cin, int Cout) {
-    return ((size_t)((Cout + 63) / 64) * ((Cin + 7) / 8) * 36 * 512 + 1024) * sizeof(float);
+    return ((size_t)((Cout + 63) / 64) * ((Cin + 7) / 8) * 36 * 512 + SIV_WPD * 512) * sizeof(float);
 }
 
 // stat_part (optional): receives [bricks][2][Cout] per-brick sums / sums of squares of the bias-free
