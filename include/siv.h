@@ -124,6 +124,18 @@ int siv_preprocess(const float* voxels, float* out, int B, long n, float cut_ran
  * applied first).  in and out are [B][D][H][W] fp32 and must not alias. */
 int siv_flip_shift(const float* in, const int* params, float* out, int B, int D, int H, int W,
                    siv_stream_t stream);
+/* siv_affine_resample: trilinear resampling of each volume under an affine map of voxel indices,
+ * the device form of the transform the reference applies before _preprocess
+ * (utils/data_load.py:21-22 with tio.transforms.RandomAffine(degrees=10), aug-z-1200main.py:106-119:
+ * small random rotation and scaling about the image centre, linear interpolation, padding with the
+ * image minimum).  mats is float[B][12] on the device: per volume the row-major 3x4 matrix that
+ * maps an OUTPUT index (d, h, w, 1) to the INPUT index sampled.  Each of the 8 neighbours that
+ * falls outside the volume contributes the pad value: pad_value when pad_mode == 0, the minimum of
+ * that volume when pad_mode == 1 (ws: B * 64 * 32 bytes, 8-byte aligned; unused for mode 0).
+ * in and out are [B][D][H][W] fp32 and must not alias. */
+int siv_affine_resample(const float* in, const float* mats, float* out, int B, int D, int H, int W,
+                        int pad_mode, float pad_value, void* ws, size_t ws_bytes,
+                        siv_stream_t stream);
 
 /* ---- BatchNorm3d (+ residual + activation + AvgPool3d + Dropout) ----------------
  * siv_bn_stats: training-mode batch statistics of nn.BatchNorm3d (models/models.py:18,22,

@@ -550,3 +550,36 @@ def flip_shift(vol, flips, shifts):
         dst.append(slice(max(0, sft), min(n, n + sft)))
     res[tuple(dst)] = out[tuple(src)]
     return res
+
+
+def affine_resample(vol, mat, pad="minimum"):
+    """Definition of the trilinear affine resampling the device augmentation performs (the
+    reference's augmentation is torchio's RandomAffine(degrees=10), aug-z-1200main.py:106-119,
+    with SimpleITK doing the resampling; neither is installed here -- parity with them is
+    unpinned; this restatement is pinned against scipy.ndimage.affine_transform(order=1,
+    mode='grid-constant') in the tests).  vol: (D, H, W) numpy; mat: (3, 4), output index ->
+    input index; each of the 8 neighbours outside the volume contributes `pad` (a number, or
+    "minimum" for vol.min()).  Computed in float64."""
+    import numpy as np
+    v = np.asarray(vol, dtype=np.float64)
+    cval = float(v.min()) if isinstance(pad, str) else float(pad)
+    a = np.asarray(mat, dtype=np.float64).reshape(3, 4)
+    dims = v.shape
+    grid = np.stack(np.meshgrid(*[np.arange(n, dtype=np.float64) for n in dims], indexing="ij"), 0)
+    pts = np.tensordot(a[:, :3], grid, axes=1) + a[:, 3].reshape(3, 1, 1, 1)
+    base = np.floor(pts)
+    frac = pts - base
+    base = base.astype(np.int64)
+    out = np.zeros(dims, dtype=np.float64)
+    for c in range(8):
+        off = ((c >> 2) & 1, (c >> 1) & 1, c & 1)
+        wgt = np.ones(dims, dtype=np.float64)
+        ok = np.ones(dims, dtype=bool)
+        idx = []
+        for ax in range(3):
+            wgt = wgt * (frac[ax] if off[ax] else 1.0 - frac[ax])
+            i = base[ax] + off[ax]
+            ok &= (i >= 0) & (i < dims[ax])
+            idx.append(np.clip(i, 0, dims[ax] - 1))
+        out += wgt * np.where(ok, v[idx[0], idx[1], idx[2]], cval)
+    return out

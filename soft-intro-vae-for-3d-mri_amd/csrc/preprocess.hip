@@ -105,6 +105,62 @@ __global__ __launch_bounds__(256) void flip_shift_k(const float* __restrict__ in
     }
 }
 
+
+// Trilinear resampling under a per-volume affine map of voxel indices:
+//   out[b][d][h][w] = sum over the 8 neighbours of p = A_b * (d, h, w, 1) of weight * value,
+// where a neighbour outside the volume contributes the pad value (the result is continuous in p).
+// mats: float[B][12], the 3x4 matrix A_b row-major, mapping OUTPUT indices to INPUT indices.
+// pad_mode 0: pad_value; 1: the minimum of volume b, taken from the partials of pp_reduce_k.
+__global__ __launch_bounds__(256) void affine_resample_k(const float* __restrict__ in,
+                                                         const float* __restrict__ mats,
+                                                         float* __restrict__ out, int D, int H, int W,
+                                                         int pad_mode, float pad_value,
+                                                         const double* __restrict__ part, int nblk) {
+    __shared__ float prm[13];
+    if (threadIdx.x < 12) prm[threadIdx.x] = mats[blockIdx.y * 12 + threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 128) {
+        float mn = pad_value;
+        if (pad_mode == 1) {
+            double m = INFINITY;
+            for (int b = threadIdx.x - 64; b < nblk; b += 64) m = fmin(m, part[((long)blockIdx.y * nblk + b) * 4 + 2]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o, 64));
+            mn = (float)m;
+        }
+        if (threadIdx.x == 64) prm[12] = mn;
+    }
+    __syncthreads();
+    const float pad = prm[12];
+    const long n = (long)D * H * W;
+    const float* p = in + (long)blockIdx.y * n;
+    float* o = out + (long)blockIdx.y * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float w = (float)(i % W), h = (float)((i / W) % H), d = (float)(i / ((long)W * H));
+        const float pz = fmaf(prm[0], d, fmaf(prm[1], h, fmaf(prm[2], w, prm[3])));
+        const float py = fmaf(prm[4], d, fmaf(prm[5], h, fmaf(prm[6], w, prm[7])));
+        const float px = fmaf(prm[8], d, fmaf(prm[9], h, fmaf(prm[10], w, prm[11])));
+        float val = pad;
+        // further than one voxel outside on any axis: all 8 neighbours are padding
+        if (pz > -1.f && pz < (float)D && py > -1.f && py < (float)H && px > -1.f && px < (float)W) {
+            const float fz = floorf(pz), fy = floorf(py), fx = floorf(px);
+            const int z0 = (int)fz, y0 = (int)fy, x0 = (int)fx;
+            const float tz = pz - fz, ty = py - fy, tx = px - fx;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int zz = z0 + (c >> 2), yy = y0 + ((c >> 1) & 1), xx = x0 + (c & 1);
+                const float wgt = ((c >> 2) ? tz : 1.f - tz) * (((c >> 1) & 1) ? ty : 1.f - ty) *
+                                  ((c & 1) ? tx : 1.f - tx);
+                const bool ok = zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                const float v = ok ? p[((long)zz * H + yy) * W + xx] : pad;
+                acc = fmaf(wgt, v, acc);
+            }
+            val = acc;
+        }
+        o[i] = val;
+    }
+}
+
 }  // namespace siv
 
 using namespace siv;
@@ -134,5 +190,27 @@ extern "C" int siv_flip_shift(const float* in, const int* params, float* out, in
     if (g > 1024) g = 1024;
     flip_shift_k<<<dim3((unsigned)g, B), 256, 0, (hipStream_t)stream>>>(in, params, out, D, H, W);
     SIV_CHECK_LAUNCH("flip_shift");
+    return SIV_OK;
+}
+
+extern "C" int siv_affine_resample(const float* in, const float* mats, float* out, int B, int D, int H,
+                                   int W, int pad_mode, float pad_value, void* ws, size_t ws_bytes,
+                                   siv_stream_t stream) {
+    SIV_CHECK_ARG(in && mats && out && in != out, "affine_resample: bad pointer (in-place is not supported)");
+    SIV_CHECK_ARG(B > 0 && D > 0 && H > 0 && W > 0, "affine_resample: bad shape");
+    SIV_CHECK_ARG(pad_mode == 0 || pad_mode == 1, "affine_resample: pad_mode must be 0 (constant) or 1 (minimum)");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)D * H * W;
+    if (pad_mode == 1) {
+        SIV_CHECK_WS((size_t)B * PP_BLOCKS * 4 * sizeof(double), ws_bytes, "affine_resample");
+        SIV_CHECK_ARG(((uintptr_t)ws & 7) == 0, "affine_resample: workspace must be 8-byte aligned");
+        pp_reduce_k<<<dim3(PP_BLOCKS, B), 256, 0, s>>>(in, n, (double*)ws);
+        SIV_CHECK_LAUNCH("affine_resample(reduce)");
+    }
+    long g = cdiv(n, 256 * 4);
+    if (g > 1024) g = 1024;
+    affine_resample_k<<<dim3((unsigned)g, B), 256, 0, s>>>(in, mats, out, D, H, W, pad_mode, pad_value,
+                                                           (const double*)ws, PP_BLOCKS);
+    SIV_CHECK_LAUNCH("affine_resample");
     return SIV_OK;
 }

@@ -28,6 +28,7 @@ SIGNATURES = {
     "siv_add_act_bwd": [_f, _f, _f, _fl, _f, _l, _f],
     "siv_preprocess": [_f, _f, _i, _l, _fl, _f, _sz, _f],
     "siv_flip_shift": [_f, _f, _f, _i, _i, _i, _i, _f],
+    "siv_affine_resample": [_f, _f, _f, _i, _i, _i, _i, _i, _fl, _f, _sz, _f],
     "siv_bn_stats": [_f, _l, _i, _f, _f, _f, _f, _f, _fl, _f, _sz, _f],
     "siv_bn_act_fwd": [_f, _f, _f, _f, _f, _f, _f, _fl, _fl, _i, _fl, _f, _i, _i, _i, _i, _i, _f],
     "siv_bn_act_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _fl, _fl, _i, _fl, _f, _f, _f, _f, _i,

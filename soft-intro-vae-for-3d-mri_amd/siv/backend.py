@@ -254,6 +254,21 @@ class HipBackend:
                                            self._stream(v)), "siv_flip_shift")
         return out
 
+    def affine_resample(self, voxels, mats, pad="minimum"):
+        """mats: float32 (B, 3, 4) device tensor, output index -> input index; pad: "minimum" or a number."""
+        self._check_dev(voxels)
+        v = voxels.contiguous()
+        shape = v.shape
+        B, (D, H, W) = shape[0], shape[-3:]
+        assert v.numel() == B * D * H * W, tuple(shape)
+        assert mats.is_cuda and mats.dtype == torch.float32 and mats.numel() == B * 12, tuple(mats.shape)
+        out = torch.empty_like(v)
+        mode, value = (1, 0.0) if pad == "minimum" else (0, float(pad))
+        ws, wsb = self._workspace(v)
+        _lib.check(self.lib.siv_affine_resample(_p(v), _p(mats.contiguous()), _p(out), B, D, H, W, mode, value,
+                                                ws, wsb, self._stream(v)), "siv_affine_resample")
+        return out
+
     # ---- batch norm + activation tail --------------------------------------------
     def bn_stats(self, y, running_mean, running_var, nbt, momentum: float):
         self._check_dev(y, running_mean, running_var, nbt)

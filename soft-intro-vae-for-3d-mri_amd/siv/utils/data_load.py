@@ -10,7 +10,7 @@ the pageable host-to-device copy that follows it) would be the bottleneck, so he
   the reference);
 * ``DeviceLoader`` wraps any loader of raw batches: it stages each batch in pinned memory,
   copies it on a side stream one batch ahead of its use, and applies ``_preprocess`` (and,
-  optionally, the flip/shift augmentation) in libsiv on the device.  It supports ``len()`` and
+  optionally, the flip/shift and random-affine augmentations) in libsiv on the device.  It supports ``len()`` and
   ``iter()`` and yields ``(batch_on_device, labels)``, which is what ``train_soft_intro_vae``
   consumes (its ``batch.to(device)`` is then a no-op).
 """
@@ -75,10 +75,66 @@ class FlipShift:
         return get_backend().flip_shift(voxels, params.to(voxels.device, non_blocking=True))
 
 
-class DeviceLoader:
-    """Pinned, double-buffered host-to-device feed + on-device ``_preprocess``."""
+def affine_matrix(scales, degrees, dims) -> np.ndarray:
+    """3x4 matrix (float64) mapping an output voxel index to the input index it samples:
+    ``p_in = c + R S (p_out - c)`` with ``c`` the image centre ``(dims - 1) / 2``, ``S`` the
+    per-axis scaling and ``R = R2 R1 R0`` the rotations by ``degrees[k]`` about array axis k."""
+    s = np.diag(np.asarray(scales, dtype=np.float64))
+    r = np.eye(3)
+    for ax, deg in enumerate(degrees):
+        t = np.deg2rad(float(deg))
+        i, j = [k for k in range(3) if k != ax]
+        m = np.eye(3)
+        m[i, i], m[i, j], m[j, i], m[j, j] = np.cos(t), -np.sin(t), np.sin(t), np.cos(t)
+        r = m @ r
+    lin = r @ s
+    c = (np.asarray(dims, dtype=np.float64) - 1.0) / 2.0
+    return np.concatenate([lin, (c - lin @ c)[:, None]], 1)
 
-    def __init__(self, loader, device, cut_range: float = 4.0, augment: FlipShift = None):
+
+class RandomAffine:
+    """Device form of ``tio.transforms.RandomAffine`` as the reference configures it
+    (aug-z-1200main.py:106-119: ``RandomAffine(degrees=10)`` inside ``OneOf(..., p=0.35)``):
+    per volume, with probability ``p``, a rotation by ``U(-degrees, degrees)`` about each axis and
+    a scaling by ``U(1 - scales, 1 + scales)`` per axis (torchio's defaults: ``scales=0.1``,
+    ``isotropic=False``, ``center='image'``, no translation), linear interpolation, padding with
+    the image minimum.  torchio and SimpleITK are not installed where this was written, so the
+    resampling is defined here (see ``siv_affine_resample``) rather than checked against them:
+    it differs from SimpleITK's in the one-voxel shell at the volume boundary, where this one
+    blends toward the pad value.  The draws come from a host ``torch.Generator``."""
+
+    def __init__(self, scales=0.1, degrees=10.0, p=1.0, pad="minimum", seed=0, generator=None):
+        self.scales = (1.0 - float(scales), 1.0 + float(scales)) if np.isscalar(scales) else tuple(scales)
+        self.degrees = (-float(degrees), float(degrees)) if np.isscalar(degrees) else tuple(degrees)
+        self.p = float(p)
+        self.pad = pad
+        self.gen = generator if generator is not None else torch.Generator().manual_seed(seed)
+
+    def draw(self, batch: int, dims) -> torch.Tensor:
+        """(batch, 3, 4) float32 matrices; identity for the volumes the transform skips."""
+        u = torch.rand(batch, 7, generator=self.gen, dtype=torch.float64).numpy()
+        mats = np.empty((batch, 3, 4), dtype=np.float64)
+        for b in range(batch):
+            if u[b, 0] < self.p:
+                sc = self.scales[0] + (self.scales[1] - self.scales[0]) * u[b, 1:4]
+                dg = self.degrees[0] + (self.degrees[1] - self.degrees[0]) * u[b, 4:7]
+            else:
+                sc, dg = np.ones(3), np.zeros(3)
+            mats[b] = affine_matrix(sc, dg, dims)
+        return torch.from_numpy(mats.astype(np.float32))
+
+    def __call__(self, voxels: torch.Tensor, mats: torch.Tensor = None) -> torch.Tensor:
+        if mats is None:
+            mats = self.draw(voxels.shape[0], voxels.shape[-3:])
+        return get_backend().affine_resample(voxels, mats.to(voxels.device, non_blocking=True), self.pad)
+
+
+class DeviceLoader:
+    """Pinned, double-buffered host-to-device feed + on-device ``_preprocess``.  ``augment`` is a
+    callable on the raw device batch (``FlipShift``, ``RandomAffine``) or a sequence of them,
+    applied in order before ``_preprocess`` as the reference's ``transform`` is."""
+
+    def __init__(self, loader, device, cut_range: float = 4.0, augment=None):
         self.loader = loader
         self.device = torch.device(device)
         self.cut_range = cut_range
@@ -116,5 +172,6 @@ class DeviceLoader:
             torch.cuda.current_stream(self.device).wait_event(ev)
             dev.record_stream(torch.cuda.current_stream(self.device))
             if self.augment is not None:
-                dev = self.augment(dev)
+                for aug in (self.augment if isinstance(self.augment, (list, tuple)) else (self.augment,)):
+                    dev = aug(dev)
             yield preprocess(dev, self.cut_range), labels

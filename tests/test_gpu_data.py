@@ -98,3 +98,50 @@ def test_device_loader_feeds_preprocessed_batches(B):
         for j, lab in enumerate(labels.tolist()):
             ref = O.preprocess(O.flip_shift(vols[lab].astype(np.float32), prm[j, :3], prm[j, 3:]))
             np.testing.assert_allclose(batch[j].cpu().numpy(), ref, rtol=0, atol=1e-4)
+
+
+def test_affine_resample_matches_definition(B):
+    """siv_affine_resample against the oracle's definition.  Tolerance: the kernel computes the
+    sample position in fp32 (error ~1e-5 voxel at index ~100) and the data vary by O(1) per voxel,
+    so 2e-4 absolute on data in [0, 1) (+ the pad value's magnitude)."""
+    import siv.utils.data_load as DL
+    rs = np.random.RandomState(21)
+    vols = rs.rand(4, 40, 48, 36).astype(np.float32)
+    vols[1] -= 0.5
+    dims = vols.shape[1:]
+    mats = np.stack([np.eye(3, 4),
+                     DL.affine_matrix((1.0, 1.0, 1.0), (10.0, 0.0, 0.0), dims),
+                     DL.affine_matrix((0.9, 1.1, 1.05), (-7.0, 4.0, 9.5), dims),
+                     DL.affine_matrix((1.1, 0.95, 0.9), (3.0, -10.0, 1.0), dims)]).astype(np.float32)
+    x, m = torch.from_numpy(vols).cuda(), torch.from_numpy(mats).cuda()
+    for pad in ("minimum", 0.0, -1.25):
+        out = B.affine_resample(x, m, pad).cpu().numpy()
+        for i in range(4):
+            np.testing.assert_allclose(out[i], O.affine_resample(vols[i], mats[i], pad), rtol=0, atol=2e-4)
+        np.testing.assert_array_equal(out[0], vols[0])                  # the identity is exact
+    # RandomAffine: same draws -> same volumes; skipped volumes come back unchanged
+    aug = DL.RandomAffine(degrees=10, p=0.5, seed=9)
+    mm = aug.draw(4, dims)
+    got = aug(x, mm).cpu().numpy()
+    for i in range(4):
+        np.testing.assert_allclose(got[i], O.affine_resample(vols[i], mm[i].numpy()), rtol=0, atol=2e-4)
+    # bad arguments are reported, not executed
+    import siv._lib as L
+    with pytest.raises(RuntimeError):
+        L.check(B.lib.siv_affine_resample(x.data_ptr(), m.data_ptr(), x.data_ptr(), 1, 2, 2, 2, 0, 0.0, None, 0, None),
+                "siv_affine_resample")
+
+
+def test_device_loader_with_affine_then_preprocess(B):
+    import siv.utils.data_load as DL
+    rs = np.random.RandomState(5)
+    vols = [np.abs(rs.randn(16, 20, 12)).astype(np.float32) for _ in range(4)]
+    ds = DL.BrainDataset(vols, list(range(4)))
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False)
+    aug = DL.RandomAffine(degrees=10, p=1.0, seed=2)
+    ref_aug = DL.RandomAffine(degrees=10, p=1.0, seed=2)
+    for batch, labels in DL.DeviceLoader(loader, "cuda:0", augment=[aug]):
+        mats = ref_aug.draw(2, (16, 20, 12)).numpy()
+        for j, lab in enumerate(labels.tolist()):
+            ref = O.preprocess(O.affine_resample(vols[lab], mats[j]).astype(np.float32))
+            np.testing.assert_allclose(batch[j].cpu().numpy(), ref, rtol=0, atol=5e-4)
