@@ -1,0 +1,317 @@
+// 3x3x3 convolution of a nearest-neighbour x2 upsampled volume without the redundant arithmetic.
+//
+// After the upsample, output voxel 2i+a (a = 0/1 its parity along an axis) reads the upsampled
+// input at 2i+a-1, 2i+a, 2i+a+1, i.e. the LOW-RESOLUTION input at
+//     a = 0:  i-1, i, i        a = 1:  i, i, i+1
+// so along every axis only two distinct inputs are touched and the three taps collapse to two with
+// pre-summed weights (a = 0: {w0, w1+w2};  a = 1: {w0+w1, w2}).  In 3-D each of the 8 output parity
+// classes is a 2x2x2 convolution of the low-resolution input: 8 multiply-adds per output and channel
+// pair instead of 27.  Arithmetic stays fp32; the only change in rounding is the pre-summation of
+// the weights.
+//
+//   M rows  = low-resolution voxels of a brick (128 or 120), N = 64 output channels
+//   K       = 8 collapsed taps x Cin per parity class
+//   a block = one brick x one parity along D; the 4 (H, W) parity classes are 4 accumulator sets that
+//             share one staged low-resolution halo
+#include "siv_common.h"
+
+#ifndef SIV_UPD
+#define SIV_UPD 4      // weight-fragment prefetch distance in taps (divides 32)
+#endif
+
+namespace siv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// LBD x LBH x LBW: low-resolution brick
+template <int LBD_, int LBH_, int LBW_>
+struct UpCfg {
+    static constexpr int LBD = LBD_, LBH = LBH_, LBW = LBW_;
+    static constexpr int CK = 8, CKP = 12;
+    static constexpr int M = LBD * LBH * LBW;             // rows in use (<= 128)
+    static constexpr int WM = 2, WN = 2, NW = 4, NTHR = 256, NT = 64, AM = 2;
+    static constexpr int HD = LBD + 1, HH = LBH + 2, HW = LBW + 2;
+    static constexpr int HV = HD * HH * HW;               // halo voxels
+    static constexpr int NH = (HV * 2 + NTHR - 1) / NTHR; // float4 halo items per thread and chunk
+    static constexpr int V_FLOATS = HV * CKP;
+    static constexpr int TAPS = 32;                       // (collapsed tap, H parity, W parity)
+    static constexpr int SLICE = NT * 8;
+    static constexpr int EPI_STRIDE = 40, EPI_FLOATS = 32 * EPI_STRIDE;
+    static constexpr int LDS_FLOATS = V_FLOATS > NW * EPI_FLOATS ? V_FLOATS : NW * EPI_FLOATS;
+    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+    static_assert(M <= 128 && M > 96, "two row tiles per wave, two waves along M");
+};
+
+// x: [N][D/2][H/2][W/2][Cin]; y: [N][D][H][W][Cout]; D, H, W even.  wp: see k2_up_pack_weights.
+template <int LBD, int LBH, int LBW>
+__global__ __launch_bounds__(256, 2) void k2_up_fwd(const float* __restrict__ x,
+                                                    const float* __restrict__ wp,
+                                                    const float* __restrict__ bias,
+                                                    float* __restrict__ y, int N, int D, int H, int W,
+                                                    int Cin, int Cout, int nbd, int nbh, int nbw,
+                                                    float* __restrict__ stat_part) {
+    using C = UpCfg<LBD, LBH, LBW>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // each XCD walks one contiguous eighth of the block list; the two D parities of a brick are
+    // neighbours in it (they read the same input)
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    const int ad = b & 1; b >>= 1;
+    const int bx = b % nbw; b /= nbw;
+    const int by = b % nbh; b /= nbh;
+    const int bz = b % nbd;
+    const int n = b / nbd;
+    const int z0 = bz * LBD, y0 = by * LBH, x0 = bx * LBW;      // low-resolution origin of the brick
+    const int co0 = blockIdx.y * C::NT;
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
+    const int nchunk = Cin / C::CK;
+
+    f32x16 acc[4][C::AM];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int a = 0; a < C::AM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][a][r] = 0.f;
+
+    // LDS offset of this lane's A row for collapsed tap (0,0,0), parities (0,0)
+    int aoff[C::AM];
+#pragma unroll
+    for (int a = 0; a < C::AM; ++a) {
+        int m = (wm * C::AM + a) * 32 + li;
+        if (m >= C::M) m = 0;                   // padding row: reads a valid voxel, never stored
+        const int dz = m / (LBH * LBW), dy = (m / LBW) % LBH, dx = m % LBW;
+        aoff[a] = ((dz * C::HH + dy) * C::HW + dx) * C::CKP + 4 * lh;
+    }
+    // this lane's B fragment inside a packed [64 co][8 ci] slice
+    const float* wlane = wp + ((long)(blockIdx.y * 2 + ad) * nchunk) * C::TAPS * C::SLICE + (wn * 32 + li) * 8 + 4 * lh;
+    constexpr int PD = SIV_UPD;
+    static_assert(C::TAPS % PD == 0, "ring index must not depend on the chunk");
+    float4 bring[PD];
+
+    // halo staging: item = (halo voxel, channel half); unconditional loads (out-of-volume voxels read
+    // voxel 0 and are zeroed when consumed), addresses hoisted out of the chunk loop
+    float4 hreg[C::NH];
+    long hoff[C::NH];
+    unsigned hmask = 0;
+#pragma unroll
+    for (int i = 0; i < C::NH; ++i) {
+        const int idx = tid + C::NTHR * i;
+        const int hv = idx >> 1, q = idx & 1;
+        const int hx = hv % C::HW, hy = (hv / C::HW) % C::HH, hz = hv / (C::HW * C::HH);
+        const int gz = z0 + ad - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = hv < C::HV && gz >= 0 && gz < Dl && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl;
+        hoff[i] = ok ? ((((long)n * Dl + gz) * Hl + gy) * Wl + gx) * Cin + 4 * q : 0;
+        hmask |= (unsigned)ok << i;
+    }
+    auto load_halo = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < C::NH; ++i) hreg[i] = *reinterpret_cast<const float4*>(x + hoff[i] + c0);
+    };
+    load_halo(0);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) bring[i] = *reinterpret_cast<const float4*>(wlane + i * C::SLICE);
+    // pin the first loads: the loop is then entered with nothing in flight and the compiler counts,
+    // per wait, the younger loads that may stay outstanding (loads return in order)
+#define SIV_PIN(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
+#pragma unroll
+    for (int i = 0; i < C::NH; ++i) SIV_PIN(hreg[i]);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) SIV_PIN(bring[i]);
+#undef SIV_PIN
+
+    for (int cc = 0; cc < nchunk; ++cc) {
+        __syncthreads();  // previous chunk's MFMAs are done with the halo
+#pragma unroll
+        for (int i = 0; i < C::NH; ++i) {
+            const int idx = tid + C::NTHR * i;
+            if (!((hmask >> i) & 1)) hreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((idx >> 1) < C::HV)
+                *reinterpret_cast<float4*>(lds + (idx >> 1) * C::CKP + 4 * (idx & 1)) = hreg[i];
+        }
+        __syncthreads();
+        load_halo((cc + 1 < nchunk ? cc + 1 : cc) * C::CK);
+        const float* wc = wlane + (long)cc * C::TAPS * C::SLICE;
+        float4 anext[C::AM];
+#pragma unroll
+        for (int a = 0; a < C::AM; ++a) anext[a] = *reinterpret_cast<const float4*>(lds + aoff[a]);
+#pragma unroll
+        for (int t = 0; t < C::TAPS; ++t) {
+            const int pos = t & 3;               // (H parity, W parity): the accumulator set
+            float4 av[C::AM];
+            const float4 bv = bring[t % PD];
+#pragma unroll
+            for (int a = 0; a < C::AM; ++a) av[a] = anext[a];
+            bring[t % PD] = *reinterpret_cast<const float4*>(wc + (t + PD) * C::SLICE);
+            if (t + 1 < C::TAPS) {
+                const int t1 = t + 1;
+                const int ah = (t1 >> 1) & 1, aw = t1 & 1, sd = t1 >> 4, sh = (t1 >> 3) & 1, sw = (t1 >> 2) & 1;
+                const int tapoff = ((sd * C::HH + ah + sh) * C::HW + aw + sw) * C::CKP;
+#pragma unroll
+                for (int a = 0; a < C::AM; ++a)
+                    anext[a] = *reinterpret_cast<const float4*>(lds + aoff[a] + tapoff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#define SIV_USTEP(F)                                                                        \
+    _Pragma("unroll") for (int a = 0; a < C::AM; ++a)                                       \
+        acc[pos][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].F, bv.F, acc[pos][a], 0, 0, 0);
+            SIV_USTEP(x)
+            SIV_USTEP(y)
+            SIV_USTEP(z)
+            SIV_USTEP(w)
+#undef SIV_USTEP
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // store: per row tile and parity class, transpose the 32x32 result through this wave's slice of
+    // LDS and write 16-byte channel runs.  When stat_part is given the block also emits, per output
+    // channel, the sum and the sum of squares of its (bias-free) outputs.
+    float* tile = lds + wave * C::EPI_FLOATS;
+    const int cq = lane & 7;
+    const int co = co0 + wn * 32 + 4 * cq;
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && co < Cout) bq = *reinterpret_cast<const float4*>(bias + co);
+    const int orig_b = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;     // this lane's column (channel co0 + wn*32 + li), its 16 rows per tile
+#pragma unroll
+    for (int a = 0; a < C::AM; ++a) {
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[pos][a][r];
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                tile[row * C::EPI_STRIDE + li] = v;
+                if (stat_part) {
+                    const int m = (wm * C::AM + a) * 32 + row;
+                    const int gz = z0 + m / (LBH * LBW), gy = y0 + (m / LBW) % LBH, gx = x0 + m % LBW;
+                    if (m < C::M && gz < Dl && gy < Hl && gx < Wl) {
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + (lane >> 3);
+                const int m = (wm * C::AM + a) * 32 + row;
+                const int gz = z0 + m / (LBH * LBW), gy = y0 + (m / LBW) % LBH, gx = x0 + m % LBW;
+                float4 v = *reinterpret_cast<const float4*>(tile + row * C::EPI_STRIDE + 4 * cq);
+                v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                if (m < C::M && gz < Dl && gy < Hl && gx < Wl && co < Cout) {
+                    const long o = (((long)n * D + 2 * gz + ad) * H + 2 * gy + (pos >> 1)) * W + 2 * gx + (pos & 1);
+                    *reinterpret_cast<float4*>(y + o * Cout + co) = v;
+                }
+            }
+        }
+    }
+    if (stat_part) {
+        s1 += __shfl_xor(s1, 32, 64);      // the two lane halves hold the same column
+        s2 += __shfl_xor(s2, 32, 64);
+        __syncthreads();
+        float* red = lds;                  // [2 (wm)][2 (sum, sumsq)][64 co]
+        if (lh == 0) {
+            red[(wm * 2 + 0) * 64 + wn * 32 + li] = s1;
+            red[(wm * 2 + 1) * 64 + wn * 32 + li] = s2;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int k = tid >> 6, c = tid & 63;
+            if (co0 + c < Cout)
+                stat_part[((long)orig_b * 2 + k) * Cout + co0 + c] = red[k * 64 + c] + red[(2 + k) * 64 + c];
+        }
+    }
+}
+
+// Along one axis, the original taps k that collapse onto source s (0/1) for output parity a:
+//   a = 0: s = 0 <- {0}, s = 1 <- {1, 2};   a = 1: s = 0 <- {0, 1}, s = 1 <- {2}
+__device__ __forceinline__ void collapsed_range(int a, int s, int& lo, int& hi) {
+    lo = a == 0 ? (s == 0 ? 0 : 1) : (s == 0 ? 0 : 2);
+    hi = a == 0 ? (s == 0 ? 0 : 2) : (s == 0 ? 1 : 2);
+}
+
+// Packed, pre-summed weights: wp[ct][ad][cc][t = (sd, sh, sw, ah, aw)][co (64)][ci (8)] from
+// w[Kout][27][Kin]; zero padded in co.
+__global__ __launch_bounds__(256) void k2_up_pack_weights(const float* __restrict__ w,
+                                                          float* __restrict__ wp, int Kin, int Kout) {
+    const int nchunk = Kin / 8, ntile = (Kout + 63) / 64;
+    const long total = (long)ntile * 2 * nchunk * 32 * 64 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        long r = i >> 3;
+        const int co = (int)(r & 63); r >>= 6;
+        const int t = (int)(r & 31); r >>= 5;
+        const int cc = (int)(r % nchunk); r /= nchunk;
+        const int ad = (int)(r & 1);
+        const int ct = (int)(r >> 1);
+        const int aw = t & 1, ah = (t >> 1) & 1, sw = (t >> 2) & 1, sh = (t >> 3) & 1, sd = t >> 4;
+        const int kco = ct * 64 + co, kci = cc * 8 + j;
+        float v = 0.f;
+        if (kco < Kout) {
+            int d0, d1, h0, h1, w0, w1;
+            collapsed_range(ad, sd, d0, d1);
+            collapsed_range(ah, sh, h0, h1);
+            collapsed_range(aw, sw, w0, w1);
+            for (int kd = d0; kd <= d1; ++kd)
+                for (int kh = h0; kh <= h1; ++kh)
+                    for (int kw = w0; kw <= w1; ++kw) v += w[((long)kco * 27 + (kd * 3 + kh) * 3 + kw) * Kin + kci];
+        }
+        wp[i] = v;
+    }
+}
+
+static bool up_wide10(int W) { return (W / 2) % 10 == 0 && (W / 2) % 8 != 0; }
+
+bool k2_up_fwd_supported(int Cin, int Cout) { return Cin % 8 == 0 && Cout % 64 == 0; }
+size_t k2_up_fwd_ws_bytes(int Cin, int Cout) {
+    return ((size_t)(Cout / 64) * 2 * (Cin / 8) * 32 * 512 + SIV_UPD * 512) * sizeof(float);
+}
+// number of [2][Cout] partial-statistics rows the kernel emits (D, H, W: output extents)
+long k2_up_fwd_blocks(int N, int D, int H, int W) {
+    if (up_wide10(W)) return (long)N * (D / 2) * cdiv(H / 2, 12) * cdiv(W / 2, 10) * 2;
+    return (long)N * cdiv(D / 2, 2) * cdiv(H / 2, 8) * cdiv(W / 2, 8) * 2;
+}
+
+template <int LBD, int LBH, int LBW>
+static int up_launch_cfg(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H,
+                         int W, int Cin, int Cout, hipStream_t s, float* stat_part) {
+    using C = UpCfg<LBD, LBH, LBW>;
+    const int nbd = (int)cdiv(D / 2, LBD), nbh = (int)cdiv(H / 2, LBH), nbw = (int)cdiv(W / 2, LBW);
+    const long nblk = (long)N * nbd * nbh * nbw * 2;
+    if (nblk > 0x7fffffffL) {
+        set_error("conv3d_k3(upsampled): too many bricks");
+        return SIV_EINVAL;
+    }
+    k2_up_fwd<LBD, LBH, LBW><<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 256, C::LDS_BYTES, s>>>(
+        x, wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part);
+    SIV_CHECK_LAUNCH("conv3d_k3(upsampled)");
+    return SIV_OK;
+}
+
+// x: [N][D/2][H/2][W/2][Cin] -> y: [N][D][H][W][Cout].  stat_part (optional): receives
+// [k2_up_fwd_blocks()][2][Cout] per-block sums / sums of squares of the bias-free output; it must not
+// overlap the first k2_up_fwd_ws_bytes() bytes of ws.
+int k2_up_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H,
+                     int W, int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t s, float* stat_part) {
+    SIV_CHECK_WS(k2_up_fwd_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(upsampled)");
+    float* wp = (float*)ws;
+    const long total = (long)(Cout / 64) * 2 * (Cin / 8) * 32 * 512;
+    long g = cdiv(total, 256);
+    if (g > 4096) g = 4096;
+    k2_up_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout);
+    SIV_CHECK_LAUNCH("conv3d_k3(pack upsampled weights)");
+    if (up_wide10(W)) return up_launch_cfg<1, 12, 10>(x, wp, bias, y, N, D, H, W, Cin, Cout, s, stat_part);
+    return up_launch_cfg<2, 8, 8>(x, wp, bias, y, N, D, H, W, Cin, Cout, s, stat_part);
+}
+
+}  // namespace siv

@@ -38,6 +38,12 @@ int k3_fwd_wino_launch(const float*, const float*, const float*, float*, int, in
                        int, int, void*, size_t, hipStream_t, float* stat_part);
 long k3_fwd_wino_bricks(int N, int D, int H, int W);
 size_t k3_fwd_wino_ws_bytes(int Cin, int Cout);
+// conv_up.hip
+bool k2_up_fwd_supported(int Cin, int Cout);
+size_t k2_up_fwd_ws_bytes(int Cin, int Cout);
+long k2_up_fwd_blocks(int N, int D, int H, int W);
+int k2_up_fwd_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int, void*,
+                     size_t, hipStream_t, float*);
 // bn_act.hip
 int bn_finalize_launch(const float*, const float*, int, long, int, float*, float*, float*, float*,
                        int64_t*, float, hipStream_t);
@@ -69,6 +75,11 @@ static bool use_wino(int path, bool aligned, int N, int D, int H, int W, int Cin
     return g_auto_wino && (long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8) * (Cout / 64) >= 512;
 }
 
+// the collapsed-tap kernel for convolutions of an upsampled input (auto and "specialised" paths)
+static bool use_up(int path, bool aligned, int ups, int Cin, int Cout) {
+    return ups == 2 && (path == 0 || path == 2) && aligned && k2_up_fwd_supported(Cin, Cout);
+}
+
 }  // namespace siv
 
 using namespace siv;
@@ -93,6 +104,8 @@ extern "C" int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bi
     const bool al = aligned16(x) && aligned16(w) && aligned16(y) && aligned16(ws);
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
         return k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s);
+    if (use_up(path, al, ups, Cin, Cout))
+        return k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, nullptr);
     if (use_wino(path, al, N, D, H, W, Cin, Cout))
         return k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s, nullptr);
     if (path != 1 && al && k3_fwd_mfma_supported(Cin, Cout))
@@ -116,6 +129,16 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
     hipStream_t s = (hipStream_t)stream;
     const long M = (long)N * D * H * W;
     const bool al = aligned16(x) && aligned16(w) && aligned16(y) && aligned16(ws);
+    if (use_up(conv_path(), al, ups, Cin, Cout)) {
+        const size_t wbytes = align256(k2_up_fwd_ws_bytes(Cin, Cout));
+        const long nblk = k2_up_fwd_blocks(N, D, H, W);
+        SIV_CHECK_WS(wbytes + (size_t)nblk * 2 * Cout * sizeof(float), ws_bytes, "conv3d_k3_fwd_bnstats");
+        float* part = (float*)((char*)ws + wbytes);
+        rc = k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, part);
+        if (rc) return rc;
+        return bn_finalize_launch(bias, part, (int)nblk, M, Cout, mean, var, running_mean, running_var,
+                                  num_batches_tracked, momentum, s);
+    }
     if (use_wino(conv_path(), al, N, D, H, W, Cin, Cout)) {
         // the convolution's epilogue emits per-brick sums of its bias-free output
         const size_t wbytes = align256(k3_fwd_wino_ws_bytes(Cin, Cout));

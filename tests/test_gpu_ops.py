@@ -79,6 +79,10 @@ CONV_CASES = [
     (8, 64, (8, 12, 8), 1, 1, 3), (64, 64, (5, 7, 9), 1, 1, 3), (64, 128, (8, 8, 16), 2, 1, 3),
     (64, 64, (8, 12, 8), 2, 2, 3), (16, 64, (10, 24, 20), 1, 1, 3), (128, 64, (4, 8, 8), 1, 2, 3),
     (72, 64, (4, 6, 10), 1, 1, 3), (64, 64, (16, 16, 16), 1, 1, 3),
+    # upsampled input through the collapsed-tap kernel (automatic path): odd low-resolution extents,
+    # partial bricks, 10- and 20-wide low-resolution volumes, two output-channel tiles
+    (8, 64, (6, 10, 14), 2, 2, 0), (64, 128, (4, 24, 40), 1, 2, 0), (24, 64, (2, 2, 2), 3, 2, 0),
+    (16, 64, (6, 26, 18), 1, 2, 0),
     # the same wide shapes through the generic kernels (cross-check of the dispatcher)
     (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
 ]
@@ -385,6 +389,8 @@ def test_add_act(B, shape):
 @pytest.mark.parametrize("cin,cout,dims,n,ups,path,use_bias", [
     (64, 64, (8, 12, 8), 2, 1, 3, False), (8, 64, (5, 7, 9), 3, 1, 3, True), (64, 128, (8, 8, 16), 1, 2, 3, True),
     (16, 64, (10, 24, 20), 1, 1, 3, False),            # statistics from the Winograd epilogue
+    (64, 128, (8, 8, 16), 1, 2, 0, True), (16, 64, (10, 24, 20), 1, 2, 0, False),
+    (8, 64, (6, 10, 14), 2, 2, 0, True),               # ... and from the collapsed-tap (upsampled) kernel
     (4, 8, (6, 7, 5), 2, 1, 0, True), (1, 8, (8, 12, 8), 2, 1, 0, True), (64, 64, (10, 12, 10), 1, 1, 0, False),
 ])
 def test_conv_fwd_with_bn_statistics(B, cin, cout, dims, n, ups, path, use_bias):
