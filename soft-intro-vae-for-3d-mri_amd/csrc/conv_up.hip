@@ -314,4 +314,218 @@ int k2_up_fwd_launch(const float* x, const float* w, const float* bias, float* y
     return up_launch_cfg<2, 8, 8>(x, wp, bias, y, N, D, H, W, Cin, Cout, s, stat_part);
 }
 
+// ---------------------------------------------------------------------------------
+// weight gradient of the convolution of an upsampled input
+// ---------------------------------------------------------------------------------
+// With the taps collapsed as above, the weight gradient splits by output parity class p = (ad,ah,aw):
+//   G[p][s][co][ci] = sum_i dy[2i + a][co] * x[i + a - 1 + s][ci],   s in {0,1}^3
+//   dw[co][kd][kh][kw][ci] = sum_p G[p][s(ad,kd), s(ah,kh), s(aw,kw)]   (s(a,k): a=0: 0,1,1; a=1: 0,0,1)
+// i.e. 8 classes x 8 taps over the low-resolution voxels: 8 multiply-adds per output voxel and channel
+// pair instead of 27.
+//
+// Block = (range of 2x4xBW low-resolution bricks) x (parity class) x (64 co x 64 ci tile).
+// Wave w owns co half (w&1), ci half (w>>1) and the 8 collapsed taps.  Voxels are the K dimension.
+template <int BW_>
+struct UwCfg {
+    static constexpr int BD = 2, BH = 4, BW = BW_;
+    static constexpr int M = BD * BH * BW;                 // 64 (80) voxels = 32 (40) k-steps
+    static constexpr int HD = BD + 1, HH = BH + 1, HW = BW + 1;
+    static constexpr int HV = HD * HH * HW;                // 135 (165) low-resolution halo voxels
+    static constexpr int CP = 64;
+    static constexpr int NDY = M * 16 / 256;               // float4 of dy per thread
+    static constexpr int NX = (HV * 16 + 255) / 256;       // float4 of x per thread (last partial)
+    static constexpr size_t LDS_BYTES = (size_t)(M * CP + HV * CP) * sizeof(float);
+};
+
+template <int BW_>
+struct UwStage {
+    using C = UwCfg<BW_>;
+    float4 dyr[C::NDY];
+    float4 xr[C::NX];
+
+    // D, H, W: extents of dy (high resolution, even); x is [N][D/2][H/2][W/2][Cin]
+    __device__ __forceinline__ void load(const float* __restrict__ x, const float* __restrict__ dy,
+                                         long br, int ad, int ah, int aw, int co0, int ci0, int D, int H,
+                                         int W, int Cin, int Cout, int nbd, int nbh, int nbw) {
+        const int tid = threadIdx.x;
+        const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
+        long b = br;
+        const int bx = (int)(b % nbw); b /= nbw;
+        const int by = (int)(b % nbh); b /= nbh;
+        const int bz = (int)(b % nbd);
+        const int n = (int)(b / nbd);
+        const int z0 = bz * C::BD, y0 = by * C::BH, x0 = bx * C::BW;
+#pragma unroll
+        for (int i = 0; i < C::NDY; ++i) {
+            const int idx = tid + 256 * i;
+            const int m = idx >> 4, q = idx & 15;
+            const int gz = z0 + m / (C::BH * C::BW), gy = y0 + (m / C::BW) % C::BH, gx = x0 + m % C::BW;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gz < Dl && gy < Hl && gx < Wl && co0 + 4 * q < Cout)
+                v = *reinterpret_cast<const float4*>(
+                    dy + ((((long)n * D + 2 * gz + ad) * H + 2 * gy + ah) * W + 2 * gx + aw) * Cout + co0 + 4 * q);
+            dyr[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < C::NX; ++i) {
+            const int idx = tid + 256 * i;
+            const int hv = idx >> 4, q = idx & 15;
+            const int hx = hv % C::HW, hy = (hv / C::HW) % C::HH, hz = hv / (C::HW * C::HH);
+            const int gz = z0 + hz + ad - 1, gy = y0 + hy + ah - 1, gx = x0 + hx + aw - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hv < C::HV && ci0 + 4 * q < Cin && gz >= 0 && gz < Dl && gy >= 0 && gy < Hl && gx >= 0 &&
+                gx < Wl)
+                v = *reinterpret_cast<const float4*>(
+                    x + ((((long)n * Dl + gz) * Hl + gy) * Wl + gx) * Cin + ci0 + 4 * q);
+            xr[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(float* dyl, float* xl) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < C::NDY; ++i) {
+            const int idx = tid + 256 * i;
+            *reinterpret_cast<float4*>(dyl + (idx >> 4) * C::CP + 4 * (idx & 15)) = dyr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < C::NX; ++i) {
+            const int idx = tid + 256 * i;
+            if ((idx >> 4) < C::HV)
+                *reinterpret_cast<float4*>(xl + (idx >> 4) * C::CP + 4 * (idx & 15)) = xr[i];
+        }
+    }
+};
+
+template <int BW_>
+__global__ __launch_bounds__(256, 2) void k2_up_wgrad(const float* __restrict__ x,
+                                                      const float* __restrict__ dy,
+                                                      float* __restrict__ part, int N, int D, int H, int W,
+                                                      int Cin, int Cout, int nbd, int nbh, int nbw,
+                                                      int bricks_per_block) {
+    using C = UwCfg<BW_>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* dyl = lds;                 // [M voxels][64 co]
+    float* xl = lds + C::M * C::CP;   // [HV halo voxels][64 ci]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int cs = wave & 1, is = wave >> 1;
+    const int p = blockIdx.y, ad = p >> 2, ah = (p >> 1) & 1, aw = p & 1;
+    const int ntci = (Cin + 63) / 64;
+    const int co0 = (blockIdx.z / ntci) * 64, ci0 = (blockIdx.z % ntci) * 64;
+    const bool active = co0 + cs * 32 < Cout && ci0 + is * 32 < Cin;
+    const long nbricks = (long)N * nbd * nbh * nbw;
+    const long b0 = (long)blockIdx.x * bricks_per_block;
+    long b1 = b0 + bricks_per_block;
+    if (b1 > nbricks) b1 = nbricks;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    UwStage<BW_> st;
+    if (b0 < b1) st.load(x, dy, b0, ad, ah, aw, co0, ci0, D, H, W, Cin, Cout, nbd, nbh, nbw);
+    for (long br = b0; br < b1; ++br) {
+        __syncthreads();              // the previous brick's MFMAs are done with LDS
+        st.store(dyl, xl);
+        __syncthreads();
+        if (br + 1 < b1)              // next brick's global loads fly during this brick's MFMAs
+            st.load(x, dy, br + 1, ad, ah, aw, co0, ci0, D, H, W, Cin, Cout, nbd, nbh, nbw);
+        const float* ap = dyl + lh * C::CP + cs * 32 + li;
+        const float* bp = xl + lh * C::CP + is * 32 + li;
+        if (active)
+#pragma unroll 4
+        for (int kk = 0; kk < C::M / 2; ++kk) {
+            // voxels 2kk + lh: dx = 2*(kk % (BW/2)) + lh, dy = (kk / (BW/2)) % BH, dz = kk / (BW/2*BH)
+            constexpr int HB = C::BW / 2;
+            const int hbase = ((kk / (HB * C::BH)) * C::HH + (kk / HB) % C::BH) * C::HW + 2 * (kk % HB);
+            const float a = ap[2 * kk * C::CP];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float bvv = bp[(hbase + ((t >> 2) * C::HH + ((t >> 1) & 1)) * C::HW + (t & 1)) * C::CP];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bvv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // partial slab: part[blockIdx.x][co][p * 8 + s][ci]
+    float* pp = part + (long)blockIdx.x * Cout * 64 * Cin;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + cs * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int ci = ci0 + is * 32 + li;
+            if (co < Cout && ci < Cin) pp[((long)co * 64 + p * 8 + t) * Cin + ci] = acc[t][r];
+        }
+    }
+}
+
+// dw[co][k][ci] = (accumulate ? dw : 0) + sum over slabs and the 8 parity classes of
+// part[slab][co][p * 8 + s(p, k)][ci], in a fixed order
+__global__ __launch_bounds__(256) void up_wgrad_reduce(const float* __restrict__ part, int nslab, int Cin,
+                                                       int Cout, float* __restrict__ dw, int accumulate) {
+    const long n = (long)Cout * 27 * Cin;
+    const long slab = (long)Cout * 64 * Cin;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        const int k = (int)((i / Cin) % 27);
+        const long co = i / ((long)Cin * 27);
+        const int kd = k / 9, kh = (k / 3) % 3, kw = k % 3;
+        float s = 0.f;
+        for (int p = 0; p < 8; ++p) {
+            const int ad = p >> 2, ah = (p >> 1) & 1, aw = p & 1;
+            const int sd = ad == 0 ? (kd > 0) : (kd > 1), sh = ah == 0 ? (kh > 0) : (kh > 1),
+                      sw = aw == 0 ? (kw > 0) : (kw > 1);
+            const float* src = part + (co * 64 + p * 8 + sd * 4 + sh * 2 + sw) * Cin + ci;
+            float sp = 0.f;
+            for (int q = 0; q < nslab; ++q) sp += src[q * slab];
+            s += sp;
+        }
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
+}
+
+bool k2_up_wgrad_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 4 && Cout >= 8; }
+
+// x: [N][D/2][H/2][W/2][Cin], dy: [N][D][H][W][Cout], dw: [Cout][27][Cin]
+int k2_up_wgrad_launch(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Cin,
+                       int Cout, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+    const int Dl = D / 2, Hl = H / 2, Wl = W / 2;
+    const bool wide = (Wl % 10 == 0) && (Wl % 8 != 0);
+    const int nbd = (Dl + 1) / 2, nbh = (Hl + 3) / 4, nbw = wide ? Wl / 10 : (Wl + 7) / 8;
+    const long nbricks = (long)N * nbd * nbh * nbw;
+    const int tiles = ((Cout + 63) / 64) * ((Cin + 63) / 64);
+    const long wsize = (long)Cout * 64 * Cin;
+    // 8*tiles*nsplit blocks at 2 resident blocks per CU: at most two full rounds
+    long nsplit = 1024 / (8L * tiles);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > nbricks) nsplit = nbricks;
+    const long max_by_ws = (long)(ws_bytes / (wsize * sizeof(float)));
+    if (nsplit > max_by_ws) nsplit = max_by_ws;
+    if (nsplit < 1) {
+        set_error("conv3d_k3_wgrad(upsampled): workspace too small (need %zu, have %zu)",
+                  (size_t)wsize * sizeof(float), ws_bytes);
+        return SIV_EWORKSPACE;
+    }
+    const int bpb = (int)cdiv(nbricks, nsplit);
+    nsplit = cdiv(nbricks, bpb);
+    dim3 grid((unsigned)nsplit, 8, (unsigned)tiles);
+    if (wide)
+        k2_up_wgrad<10><<<grid, 256, UwCfg<10>::LDS_BYTES, s>>>(x, dy, (float*)ws, N, D, H, W, Cin, Cout, nbd, nbh,
+                                                                nbw, bpb);
+    else
+        k2_up_wgrad<8><<<grid, 256, UwCfg<8>::LDS_BYTES, s>>>(x, dy, (float*)ws, N, D, H, W, Cin, Cout, nbd, nbh,
+                                                              nbw, bpb);
+    SIV_CHECK_LAUNCH("conv3d_k3_wgrad(upsampled)");
+    long g = cdiv((long)Cout * 27 * Cin, 256);
+    if (g > 4096) g = 4096;
+    up_wgrad_reduce<<<(unsigned)g, 256, 0, s>>>((const float*)ws, (int)nsplit, Cin, Cout, dw, accumulate);
+    SIV_CHECK_LAUNCH("conv3d_k3_wgrad(upsampled reduce)");
+    return SIV_OK;
+}
+
 }  // namespace siv

@@ -44,6 +44,9 @@ size_t k2_up_fwd_ws_bytes(int Cin, int Cout);
 long k2_up_fwd_blocks(int N, int D, int H, int W);
 int k2_up_fwd_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int, void*,
                      size_t, hipStream_t, float*);
+bool k2_up_wgrad_supported(int Cin, int Cout);
+int k2_up_wgrad_launch(const float*, const float*, float*, int, int, int, int, int, int, int, void*, size_t,
+                       hipStream_t);
 // bn_act.hip
 int bn_finalize_launch(const float*, const float*, int, long, int, float*, float*, float*, float*,
                        int64_t*, float, hipStream_t);
@@ -188,7 +191,10 @@ extern "C" int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, f
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
         return k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
     if (path != 1 && al && k3_wgrad_mfma_supported(Cin, Cout)) {
-        rc = k3_wgrad_mfma_launch(x, dy, dw, N, D, H, W, Cin, Cout, ups, accumulate, ws, ws_bytes, s);
+        if (ups == 2 && (path == 0 || path == 2) && k2_up_wgrad_supported(Cin, Cout))
+            rc = k2_up_wgrad_launch(x, dy, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
+        else
+            rc = k3_wgrad_mfma_launch(x, dy, dw, N, D, H, W, Cin, Cout, ups, accumulate, ws, ws_bytes, s);
         if (rc) return rc;
         if (dbias) return colsum_launch(dy, dbias, (long)N * D * H * W, Cout, accumulate, ws, ws_bytes, s);
         return SIV_OK;
