@@ -70,6 +70,18 @@ int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const float* bias,
 int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx,
                         int N, int D, int H, int W, int Cin, int Cout,
                         void* ws, size_t ws_bytes, siv_stream_t stream);
+/* siv_conv3d_k3_dgrad_up: input gradient of siv_conv3d_k3_fwd with ups == 2, i.e. of
+ * nn.Upsample(scale_factor=2, mode="nearest") followed by nn.Conv3d(k=3, p=1)
+ * (models/models.py:57-59, models/mymodel.py:176-215), with respect to the LOW-RESOLUTION input:
+ * dx[N][D/2][H/2][W/2][Cin] = 2x2x2 sum-pool of the gradient with respect to the upsampled tensor,
+ * computed in one pass as a stride-2 convolution of dy[N][D][H][W][Cout] with the 4x4x4 kernel the
+ * 27 taps collapse to (no full-resolution intermediate).  Needs Cin % 64 == 0, Cout % 8 == 0 and
+ * 16-byte aligned pointers; siv_conv3d_k3_dgrad_up_supported returns 1 when the current conv path
+ * and the channel counts allow it, otherwise callers use siv_conv3d_k3_dgrad + siv_upsample2_bwd. */
+int siv_conv3d_k3_dgrad_up_supported(int Cin, int Cout);
+int siv_conv3d_k3_dgrad_up(const float* dy, const float* w, float* dx, int N, int D, int H, int W,
+                           int Cin, int Cout, void* ws, size_t ws_bytes, siv_stream_t stream);
+
 /* Gradient w.r.t. weight (and bias when dbias != NULL).  x as in _fwd (ups honoured).
  * accumulate != 0 adds into dw/dbias instead of overwriting them. */
 int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, float* dbias,

@@ -528,4 +528,259 @@ int k2_up_wgrad_launch(const float* x, const float* dy, float* dw, int N, int D,
     return SIV_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// input gradient of the convolution of an upsampled input
+// ---------------------------------------------------------------------------------
+// The gradient with respect to the LOW-RESOLUTION input is the 2x2x2 sum-pool of the gradient with
+// respect to the upsampled one, which makes it a stride-2 convolution of dy with a 4x4x4 kernel:
+//   dx[j][ci] = sum_{u in {-1,0,1,2}^3} sum_co q[u][co][ci] * dy[2j + u][co]
+// where along each axis q[-1] = w2, q[0] = w1 + w2, q[1] = w0 + w1, q[2] = w0 (wk = tap k of that
+// axis): 64 taps per low-resolution voxel = 8 multiply-adds per dy voxel and channel pair instead of
+// 27, and no full-resolution intermediate.
+//
+//   M rows  = low-resolution voxels of a brick (256 or 240), N = 64 input channels of the convolution
+//   K       = 64 taps x Cout, walked as (8-channel chunk, u along D): each step stages the dy planes
+//             2z + u of the brick (W-parity split, so that the stride-2 reads are unit-stride in LDS)
+//             and runs the 16 (u along H, u along W) taps on them
+template <int LBD_, int LBH_, int LBW_>
+struct UdCfg {
+    static constexpr int LBD = LBD_, LBH = LBH_, LBW = LBW_;
+    static constexpr int CK = 8, CKP = 12;
+    static constexpr int M = LBD * LBH * LBW;             // rows in use (<= 256)
+    static constexpr int NTHR = 256, NT = 64, AM = 4;     // 2 x 2 waves, 4 row tiles per wave
+    static constexpr int HH = 2 * LBH + 2, HWF = 2 * LBW + 2, HWH = LBW + 1;
+    static constexpr int PITCH = LBW == 8 ? 240 : 272;    // floats per halo row; = 16 mod 32 (bank spread)
+    static constexpr int HV = LBD * HH * HWF;             // dy voxels staged per step
+    static constexpr int NH = (HV * 2 + NTHR - 1) / NTHR;
+    static constexpr int V_FLOATS = LBD * HH * PITCH;
+    static constexpr int TAPS = 16, SLICE = NT * 8;
+    static constexpr int EPI_STRIDE = 40, EPI_FLOATS = 32 * EPI_STRIDE;
+    static constexpr size_t LDS_BYTES = (size_t)V_FLOATS * sizeof(float);
+    static_assert(PITCH >= 2 * HWH * CKP && PITCH % 32 == 16, "row pitch");
+    static_assert(M <= 256 && M > 224, "four row tiles per wave, two waves along M");
+    static_assert(V_FLOATS >= 4 * EPI_FLOATS, "epilogue tiles fit");
+};
+
+// dy: [N][D][H][W][Cout] (D, H, W even); dx: [N][D/2][H/2][W/2][Cin]; wp: see k2_up_pack_dgrad.
+template <int LBD, int LBH, int LBW>
+__global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ dy,
+                                                      const float* __restrict__ wp,
+                                                      float* __restrict__ dx, int N, int D, int H, int W,
+                                                      int Cin, int Cout, int nbd, int nbh, int nbw) {
+    using C = UdCfg<LBD, LBH, LBW>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    const int bx = b % nbw; b /= nbw;
+    const int by = b % nbh; b /= nbh;
+    const int bz = b % nbd;
+    const int n = b / nbd;
+    const int z0 = bz * LBD, y0 = by * LBH, x0 = bx * LBW;      // low-resolution origin of the brick
+    const int ci0 = blockIdx.y * C::NT;
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
+    const int nstep = (Cout / C::CK) * 4;                       // (chunk, u along D)
+
+    f32x16 acc[C::AM];
+#pragma unroll
+    for (int a = 0; a < C::AM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    // LDS offset of this lane's A row for tap (u_h, u_w) = (-1, -1)
+    int aoff[C::AM];
+#pragma unroll
+    for (int a = 0; a < C::AM; ++a) {
+        int m = (wm * C::AM + a) * 32 + li;
+        if (m >= C::M) m = 0;                   // padding row: reads a valid voxel, never stored
+        const int dz = m / (LBH * LBW), dyy = (m / LBW) % LBH, dxx = m % LBW;
+        aoff[a] = (dz * C::HH + 2 * dyy) * C::PITCH + dxx * C::CKP + 4 * lh;
+    }
+    const float* wlane = wp + (long)blockIdx.y * nstep * C::TAPS * C::SLICE + (wn * 32 + li) * 8 + 4 * lh;
+    constexpr int PD = 4;
+    float4 bring[PD];
+
+    // staging: item = (dy voxel of the staged planes, channel half).  Offsets are relative to the
+    // brick's first voxel in plane 2*z0 (always inside the tensor); the plane parity u is added per step.
+    const long plane = (long)H * W * Cout;
+    const float* base = dy + (((long)n * D + 2 * z0) * H + 2 * y0) * (long)W * Cout + (long)2 * x0 * Cout;
+    float4 hreg[C::NH];
+    int hoff[C::NH], hdst[C::NH];
+    unsigned hmask = 0, curmask = 0;
+    int hpz[C::NH];
+#pragma unroll
+    for (int i = 0; i < C::NH; ++i) {
+        const int idx = tid + C::NTHR * i;
+        const int hv = idx >> 1, q = idx & 1;
+        const int hx = hv % C::HWF, hy = (hv / C::HWF) % C::HH, pz = hv / (C::HWF * C::HH);
+        const int gy = 2 * y0 - 1 + hy, gx = 2 * x0 - 1 + hx;
+        const bool ok = hv < C::HV && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        hoff[i] = ok ? ((2 * pz * H + (hy - 1)) * W + (hx - 1)) * Cout + 4 * q : 0;
+        hpz[i] = ok ? 2 * (z0 + pz) : -4;       // high-resolution plane for u = 0 (-4: never valid)
+        hdst[i] = (pz * C::HH + hy) * C::PITCH + ((hx & 1) * C::HWH + (hx >> 1)) * C::CKP + 4 * q;
+        hmask |= (unsigned)(hv < C::HV) << i;
+    }
+    auto load_halo = [&](int step) {
+        const int c0 = (step >> 2) * C::CK, u = (step & 3) - 1;
+        unsigned mk = 0;
+#pragma unroll
+        for (int i = 0; i < C::NH; ++i) {
+            const int gz = hpz[i] + u;
+            const bool ok = gz >= 0 && gz < D;
+            const long off = ok ? (long)hoff[i] + u * plane + c0 : 0;
+            hreg[i] = *reinterpret_cast<const float4*>(base + off);
+            mk |= (unsigned)ok << i;
+        }
+        return mk;
+    };
+    unsigned nextmask = load_halo(0);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) bring[i] = *reinterpret_cast<const float4*>(wlane + i * C::SLICE);
+#define SIV_PIN(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
+#pragma unroll
+    for (int i = 0; i < C::NH; ++i) SIV_PIN(hreg[i]);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) SIV_PIN(bring[i]);
+#undef SIV_PIN
+
+    for (int step = 0; step < nstep; ++step) {
+        curmask = nextmask;
+        __syncthreads();  // previous step's MFMAs are done with the planes
+#pragma unroll
+        for (int i = 0; i < C::NH; ++i) {
+            if (!((curmask >> i) & 1)) hreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((hmask >> i) & 1) *reinterpret_cast<float4*>(lds + hdst[i]) = hreg[i];
+        }
+        __syncthreads();
+        nextmask = load_halo(step + 1 < nstep ? step + 1 : step);
+        const float* wc = wlane + (long)step * C::TAPS * C::SLICE;
+        float4 anext[C::AM];
+#pragma unroll
+        for (int a = 0; a < C::AM; ++a) anext[a] = *reinterpret_cast<const float4*>(lds + aoff[a]);
+#pragma unroll
+        for (int t = 0; t < C::TAPS; ++t) {
+            float4 av[C::AM];
+            const float4 bv = bring[t % PD];
+#pragma unroll
+            for (int a = 0; a < C::AM; ++a) av[a] = anext[a];
+            bring[t % PD] = *reinterpret_cast<const float4*>(wc + (t + PD) * C::SLICE);
+            if (t + 1 < C::TAPS) {
+                const int uh = (t + 1) >> 2, uw = (t + 1) & 3;
+                const int tapoff = uh * C::PITCH + ((uw & 1) * C::HWH + (uw >> 1)) * C::CKP;
+#pragma unroll
+                for (int a = 0; a < C::AM; ++a)
+                    anext[a] = *reinterpret_cast<const float4*>(lds + aoff[a] + tapoff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#define SIV_DSTEP(F)                                                                        \
+    _Pragma("unroll") for (int a = 0; a < C::AM; ++a)                                       \
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].F, bv.F, acc[a], 0, 0, 0);
+            SIV_DSTEP(x)
+            SIV_DSTEP(y)
+            SIV_DSTEP(z)
+            SIV_DSTEP(w)
+#undef SIV_DSTEP
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // store: transpose each 32x32 tile through this wave's slice of LDS, write 16-byte channel runs
+    float* tile = lds + wave * C::EPI_FLOATS;
+    const int cq = lane & 7;
+    const int ci = ci0 + wn * 32 + 4 * cq;
+#pragma unroll
+    for (int a = 0; a < C::AM; ++a) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * C::EPI_STRIDE + li] = acc[a][r];
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = ps * 8 + (lane >> 3);
+            const int m = (wm * C::AM + a) * 32 + row;
+            const int gz = z0 + m / (LBH * LBW), gy = y0 + (m / LBW) % LBH, gx = x0 + m % LBW;
+            const float4 v = *reinterpret_cast<const float4*>(tile + row * C::EPI_STRIDE + 4 * cq);
+            if (m < C::M && gz < Dl && gy < Hl && gx < Wl && ci < Cin)
+                *reinterpret_cast<float4*>(dx + ((((long)n * Dl + gz) * Hl + gy) * Wl + gx) * Cin + ci) = v;
+        }
+    }
+}
+
+// Packed 4x4x4 stride-2 kernel: wp[ct][cc][ud][t = (uh, uw)][ci (64)][co (8)] from w[Kout][27][Kin];
+// along an axis, offset u = -1, 0, 1, 2 (index 0..3) sums the original taps {2}, {1,2}, {0,1}, {0}.
+__global__ __launch_bounds__(256) void k2_up_pack_dgrad(const float* __restrict__ w, float* __restrict__ wp,
+                                                        int Kin, int Kout) {
+    const int nchunk = Kout / 8, ntile = (Kin + 63) / 64;
+    const long total = (long)ntile * nchunk * 64 * 64 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        long r = i >> 3;
+        const int ci = (int)(r & 63); r >>= 6;
+        const int t = (int)(r & 15); r >>= 4;
+        const int ud = (int)(r & 3); r >>= 2;
+        const int cc = (int)(r % nchunk);
+        const int ct = (int)(r / nchunk);
+        const int uh = t >> 2, uw = t & 3;
+        const int kci = ct * 64 + ci, kco = cc * 8 + j;
+        float v = 0.f;
+        if (kci < Kin) {
+            // index u -> taps [lo, hi]: 0 -> {2}, 1 -> {1,2}, 2 -> {0,1}, 3 -> {0}
+            const int d0 = ud == 0 ? 2 : ud == 1 ? 1 : 0, d1 = ud <= 1 ? 2 : ud == 2 ? 1 : 0;
+            const int h0 = uh == 0 ? 2 : uh == 1 ? 1 : 0, h1 = uh <= 1 ? 2 : uh == 2 ? 1 : 0;
+            const int w0 = uw == 0 ? 2 : uw == 1 ? 1 : 0, w1 = uw <= 1 ? 2 : uw == 2 ? 1 : 0;
+            for (int kd = d0; kd <= d1; ++kd)
+                for (int kh = h0; kh <= h1; ++kh)
+                    for (int kw = w0; kw <= w1; ++kw) v += w[((long)kco * 27 + (kd * 3 + kh) * 3 + kw) * Kin + kci];
+        }
+        wp[i] = v;
+    }
+}
+
+bool k2_up_dgrad_supported(int Cin, int Cout) { return Cout % 8 == 0 && Cin % 64 == 0; }
+size_t k2_up_dgrad_ws_bytes(int Cin, int Cout) {
+    return ((size_t)(Cin / 64) * (Cout / 8) * 64 * 512 + 4 * 512) * sizeof(float);
+}
+
+template <int LBD, int LBH, int LBW>
+static int up_dgrad_cfg(const float* dy, const float* wp, float* dx, int N, int D, int H, int W, int Cin,
+                        int Cout, hipStream_t s) {
+    using C = UdCfg<LBD, LBH, LBW>;
+    const int nbd = (int)cdiv(D / 2, LBD), nbh = (int)cdiv(H / 2, LBH), nbw = (int)cdiv(W / 2, LBW);
+    const long nblk = (long)N * nbd * nbh * nbw;
+    if (nblk > 0x7fffffffL || (long)(2 * LBD + 2) * H * W * Cout > 0x7fffffffL) {
+        set_error("conv3d_k3_dgrad(upsampled): volume too large for 32-bit brick offsets");
+        return SIV_EINVAL;
+    }
+    // more than 64 KB of dynamic LDS is an opt-in
+    if (hipFuncSetAttribute((const void*)k2_up_dgrad<LBD, LBH, LBW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)C::LDS_BYTES) != hipSuccess) {
+        set_error("conv3d_k3_dgrad(upsampled): cannot reserve %zu bytes of LDS", C::LDS_BYTES);
+        return SIV_EHIP;
+    }
+    k2_up_dgrad<LBD, LBH, LBW><<<dim3((unsigned)nblk, (unsigned)(Cin / 64)), 256, C::LDS_BYTES, s>>>(
+        dy, wp, dx, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
+    SIV_CHECK_LAUNCH("conv3d_k3_dgrad(upsampled)");
+    return SIV_OK;
+}
+
+// dy: [N][D][H][W][Cout] -> dx: [N][D/2][H/2][W/2][Cin]; w: the convolution's weights [Cout][27][Cin]
+int k2_up_dgrad_launch(const float* dy, const float* w, float* dx, int N, int D, int H, int W, int Cin,
+                       int Cout, void* ws, size_t ws_bytes, hipStream_t s) {
+    SIV_CHECK_WS(k2_up_dgrad_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3_dgrad(upsampled)");
+    float* wp = (float*)ws;
+    const long total = (long)(Cin / 64) * (Cout / 8) * 64 * 512;
+    long g = cdiv(total, 256);
+    if (g > 4096) g = 4096;
+    k2_up_pack_dgrad<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout);
+    SIV_CHECK_LAUNCH("conv3d_k3_dgrad(pack upsampled weights)");
+    if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10>(dy, wp, dx, N, D, H, W, Cin, Cout, s);
+    return up_dgrad_cfg<4, 8, 8>(dy, wp, dx, N, D, H, W, Cin, Cout, s);
+}
+
 }  // namespace siv

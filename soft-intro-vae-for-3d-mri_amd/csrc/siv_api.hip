@@ -44,6 +44,9 @@ size_t k2_up_fwd_ws_bytes(int Cin, int Cout);
 long k2_up_fwd_blocks(int N, int D, int H, int W);
 int k2_up_fwd_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int, void*,
                      size_t, hipStream_t, float*);
+bool k2_up_dgrad_supported(int Cin, int Cout);
+int k2_up_dgrad_launch(const float*, const float*, float*, int, int, int, int, int, int, void*, size_t,
+                       hipStream_t);
 bool k2_up_wgrad_supported(int Cin, int Cout);
 int k2_up_wgrad_launch(const float*, const float*, float*, int, int, int, int, int, int, int, void*, size_t,
                        hipStream_t);
@@ -177,6 +180,25 @@ extern "C" int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx, i
         return k3_fwd_mfma_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s);
     SIV_CHECK_ARG(path != 2, "conv3d_k3_dgrad: no specialised kernel for Cin=%d Cout=%d", Cin, Cout);
     return k3_dgrad_generic_launch(dy, w, dx, N, D, H, W, Cin, Cout, s);
+}
+
+extern "C" int siv_conv3d_k3_dgrad_up_supported(int Cin, int Cout) {
+    const int path = conv_path();
+    return (path == 0 || path == 2) && k2_up_dgrad_supported(Cin, Cout) ? 1 : 0;
+}
+
+extern "C" int siv_conv3d_k3_dgrad_up(const float* dy, const float* w, float* dx, int N, int D, int H,
+                                      int W, int Cin, int Cout, void* ws, size_t ws_bytes,
+                                      siv_stream_t stream) {
+    SIV_CHECK_ARG(dy && w && dx, "conv3d_k3_dgrad_up: null pointer");
+    int rc = check_conv_shape("conv3d_k3_dgrad_up", N, D, H, W, Cin, Cout, 2);
+    if (rc) return rc;
+    SIV_CHECK_ARG(aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws),
+                  "conv3d_k3_dgrad_up: pointers must be 16-byte aligned");
+    SIV_CHECK_ARG(k2_up_dgrad_supported(Cin, Cout),
+                  "conv3d_k3_dgrad_up: needs Cin %% 64 == 0 and Cout %% 8 == 0 (got Cin=%d Cout=%d); use "
+                  "siv_conv3d_k3_dgrad followed by siv_upsample2_bwd", Cin, Cout);
+    return k2_up_dgrad_launch(dy, w, dx, N, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N,

@@ -16,6 +16,8 @@ SIGNATURES = {
     "siv_conv3d_k3_fwd": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_conv3d_k3_fwd_bnstats": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _fl, _f, _sz, _f],
     "siv_conv3d_k3_dgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
+    "siv_conv3d_k3_dgrad_up": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
+    "siv_conv3d_k3_dgrad_up_supported": [_i, _i],
     "siv_conv3d_k3_wgrad": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_upsample2_bwd": [_f, _f, _i, _i, _i, _i, _i, _f],
     "siv_conv1x1_fwd": [_f, _f, _f, _f, _l, _i, _i, _f],

@@ -116,9 +116,14 @@ class HipBackend:
         dy, w = cl(dy), cl(w)
         N, Cout, D, H, W = dy.shape
         Cin = w.shape[1]
-        dx = empty_cl((N, Cin, D, H, W), dy)
         ws, wsb = self._workspace(dy)
         st = self._stream(dy)
+        if ups == 2 and self.lib.siv_conv3d_k3_dgrad_up_supported(Cin, Cout):
+            dxs = empty_cl((N, Cin, D // 2, H // 2, W // 2), dy)
+            _lib.check(self.lib.siv_conv3d_k3_dgrad_up(_p(dy), _p(w), _p(dxs), N, D, H, W, Cin, Cout, ws, wsb, st),
+                       "siv_conv3d_k3_dgrad_up")
+            return dxs
+        dx = empty_cl((N, Cin, D, H, W), dy)
         _lib.check(self.lib.siv_conv3d_k3_dgrad(_p(dy), _p(w), _p(dx), N, D, H, W, Cin, Cout, ws, wsb, st),
                    "siv_conv3d_k3_dgrad")
         if ups == 1:

@@ -83,6 +83,9 @@ CONV_CASES = [
     # partial bricks, 10- and 20-wide low-resolution volumes, two output-channel tiles
     (8, 64, (6, 10, 14), 2, 2, 0), (64, 128, (4, 24, 40), 1, 2, 0), (24, 64, (2, 2, 2), 3, 2, 0),
     (16, 64, (6, 26, 18), 1, 2, 0),
+    # ... whose input gradient runs as a stride-2 4x4x4 convolution when Cin % 64 == 0
+    (64, 8, (6, 10, 14), 2, 2, 0), (64, 16, (10, 24, 20), 1, 2, 0), (64, 64, (2, 2, 2), 1, 2, 0),
+    (128, 24, (12, 20, 18), 1, 2, 0),
     # the same wide shapes through the generic kernels (cross-check of the dispatcher)
     (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
 ]
