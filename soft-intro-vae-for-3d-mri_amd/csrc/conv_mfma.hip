@@ -311,6 +311,10 @@ bool k3_fwd_mfma_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cin >= 4 
 //           than kBig with its padded third brick column -- five waves do not spread evenly over
 //           four SIMDs -- and are not instantiated.)
 //   kN32    4x8x8 bricks with 32-channel tiles: output widths that are not multiples of 64
+// (Split-K over the input-channel chunks -- 2 or 4 blocks per output tile, partial slabs summed in a
+// second pass -- was measured on the 10x12x10 layers, 240 blocks of one wave per SIMD: 0.378 ms without,
+// 0.379 ms with 2 splits, 0.392 ms with 4.  Those layers stream each block's 3.5 MB weight tile from
+// L2 / Infinity Cache for only 80 voxels of reuse; more resident waves do not change that.  Not kept.)
 enum FwdKind { kBig, kSmall, kW10b, kN32 };
 static bool use_small_brick(int D, int H, int W) {
     auto waste = [&](int bd, int bh, int bw) {
