@@ -168,6 +168,7 @@ def main():
     last = None
     for i in range(args.steps):
         last = one_step(args.warmup + i)
+    host_elapsed = time.perf_counter() - t0     # Python + launch time only: nothing above waits for the GPU
     barrier()
     elapsed = time.perf_counter() - t0
     recording["on"] = False
@@ -212,6 +213,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "rng": "device Philox (dropout, eps, noise)"},
+            "host_enqueue_ms_per_step": round(1000.0 * host_elapsed / args.steps, 2),
             "roofline": roof,
             "losses": {k: stats[k] for k in ("lossE", "lossD", "loss_rec", "kl_real")},
         }
