@@ -464,12 +464,24 @@ __global__ __launch_bounds__(256, 2) void k2_up_wgrad(const float* __restrict__ 
     }
 }
 
-// dw[co][k][ci] = (accumulate ? dw : 0) + sum over slabs and the 8 parity classes of
-// part[slab][co][p * 8 + s(p, k)][ci], in a fixed order
-__global__ __launch_bounds__(256) void up_wgrad_reduce(const float* __restrict__ part, int nslab, int Cin,
-                                                       int Cout, float* __restrict__ dw, int accumulate) {
+// Two-stage, fixed-order reduction of the partial slabs.  Stage 1 (slab_sum_inplace) adds slabs
+// 1..nslab-1 into slab 0, one element per thread (coalesced, nslab loads deep); stage 2 maps the 64
+// (class, collapsed tap) sums onto the 27 taps:
+//   dw[co][k][ci] = (accumulate ? dw : 0) + sum_p slab0[co][p * 8 + s(p, k)][ci]
+__global__ __launch_bounds__(256) void slab_sum_inplace(float* __restrict__ part, int nslab, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 s = *reinterpret_cast<const float4*>(part + 4 * i);
+        for (int q = 1; q < nslab; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (long)q * 4 * n4 + 4 * i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(part + 4 * i) = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void up_wgrad_taps(const float* __restrict__ g, int Cin, int Cout,
+                                                     float* __restrict__ dw, int accumulate) {
     const long n = (long)Cout * 27 * Cin;
-    const long slab = (long)Cout * 64 * Cin;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int ci = (int)(i % Cin);
         const int k = (int)((i / Cin) % 27);
@@ -480,10 +492,7 @@ __global__ __launch_bounds__(256) void up_wgrad_reduce(const float* __restrict__
             const int ad = p >> 2, ah = (p >> 1) & 1, aw = p & 1;
             const int sd = ad == 0 ? (kd > 0) : (kd > 1), sh = ah == 0 ? (kh > 0) : (kh > 1),
                       sw = aw == 0 ? (kw > 0) : (kw > 1);
-            const float* src = part + (co * 64 + p * 8 + sd * 4 + sh * 2 + sw) * Cin + ci;
-            float sp = 0.f;
-            for (int q = 0; q < nslab; ++q) sp += src[q * slab];
-            s += sp;
+            s += g[(co * 64 + p * 8 + sd * 4 + sh * 2 + sw) * Cin + ci];
         }
         dw[i] = accumulate ? dw[i] + s : s;
     }
@@ -521,10 +530,16 @@ int k2_up_wgrad_launch(const float* x, const float* dy, float* dw, int N, int D,
         k2_up_wgrad<8><<<grid, 256, UwCfg<8>::LDS_BYTES, s>>>(x, dy, (float*)ws, N, D, H, W, Cin, Cout, nbd, nbh,
                                                               nbw, bpb);
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(upsampled)");
-    long g = cdiv((long)Cout * 27 * Cin, 256);
+    long g = cdiv(wsize / 4, 256);        // Cin % 4 == 0: whole float4s
     if (g > 4096) g = 4096;
-    up_wgrad_reduce<<<(unsigned)g, 256, 0, s>>>((const float*)ws, (int)nsplit, Cin, Cout, dw, accumulate);
-    SIV_CHECK_LAUNCH("conv3d_k3_wgrad(upsampled reduce)");
+    if (nsplit > 1) {
+        slab_sum_inplace<<<(unsigned)g, 256, 0, s>>>((float*)ws, (int)nsplit, wsize / 4);
+        SIV_CHECK_LAUNCH("conv3d_k3_wgrad(upsampled slab sum)");
+    }
+    g = cdiv((long)Cout * 27 * Cin, 256);
+    if (g > 4096) g = 4096;
+    up_wgrad_taps<<<(unsigned)g, 256, 0, s>>>((const float*)ws, Cin, Cout, dw, accumulate);
+    SIV_CHECK_LAUNCH("conv3d_k3_wgrad(upsampled taps)");
     return SIV_OK;
 }
 
