@@ -14,6 +14,7 @@
 //   a block = one brick x one parity along D; the 4 (H, W) parity classes are 4 accumulator sets that
 //             share one staged low-resolution halo
 #include "siv_common.h"
+#include "split_bf16.h"
 
 #ifndef SIV_UPD
 #define SIV_UPD 4      // weight-fragment prefetch distance in taps (divides 32)
@@ -270,11 +271,247 @@ __global__ __launch_bounds__(256) void k2_up_pack_weights(const float* __restric
     }
 }
 
+// The same convolution with every fp32 product formed from three bf16 pieces per operand on the bf16
+// matrix cores (scheme and operand packing: conv_wino_b3.hip).  The staged halo holds [h | m | l] pieces
+// of 8 channels per voxel (48 bytes, the fp32 footprint); wp: see k2_up_pack_weights_b3.
+template <int LBD, int LBH, int LBW>
+__global__ __launch_bounds__(256, 2) void k2_up_fwd_b3(const float* __restrict__ x,
+                                                       const uint4* __restrict__ wp,
+                                                    const float* __restrict__ bias,
+                                                    float* __restrict__ y, int N, int D, int H, int W,
+                                                    int Cin, int Cout, int nbd, int nbh, int nbw,
+                                                    float* __restrict__ stat_part) {
+    using C = UpCfg<LBD, LBH, LBW>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    // each XCD walks one contiguous eighth of the block list; the two D parities of a brick are
+    // neighbours in it (they read the same input)
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    const int ad = b & 1; b >>= 1;
+    const int bx = b % nbw; b /= nbw;
+    const int by = b % nbh; b /= nbh;
+    const int bz = b % nbd;
+    const int n = b / nbd;
+    const int z0 = bz * LBD, y0 = by * LBH, x0 = bx * LBW;      // low-resolution origin of the brick
+    const int co0 = blockIdx.y * C::NT;
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
+    const int nchunk = Cin / C::CK;
+
+    f32x16 acc[4][C::AM];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int a = 0; a < C::AM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][a][r] = 0.f;
+
+    // LDS offsets of this lane's three A operands (pieces h|h, m|h, l|m by lane half), tap 0, parities (0,0)
+    int aoff1[C::AM], aoff2[C::AM], aoff3[C::AM];
+#pragma unroll
+    for (int a = 0; a < C::AM; ++a) {
+        int m = (wm * C::AM + a) * 32 + li;
+        if (m >= C::M) m = 0;                   // padding row: reads a valid voxel, never stored
+        const int dz = m / (LBH * LBW), dy = (m / LBW) % LBH, dx = m % LBW;
+        const int row = ((dz * C::HH + dy) * C::HW + dx) * C::CKP;
+        aoff1[a] = row;
+        aoff2[a] = row + (lh ? 0 : 4);
+        aoff3[a] = row + (lh ? 4 : 8);
+    }
+    // this lane's two B operands of a tap: slices of [64 co][2 lane halves][8 ci] bf16, 256 uint4 per tap
+    const uint4* wlane = wp + ((long)(blockIdx.y * 2 + ad) * nchunk) * C::TAPS * 256 + (wn * 32 + li) * 2 + lh;
+    constexpr int PD = 4;
+    uint4 bxr[PD], byr[PD];
+
+    // halo staging: item = (halo voxel, channel half); unconditional loads (out-of-volume voxels read
+    // voxel 0 and are zeroed when consumed), addresses hoisted out of the chunk loop
+    float4 hreg[C::NH];
+    long hoff[C::NH];
+    unsigned hmask = 0;
+#pragma unroll
+    for (int i = 0; i < C::NH; ++i) {
+        const int idx = tid + C::NTHR * i;
+        const int hv = idx >> 1, q = idx & 1;
+        const int hx = hv % C::HW, hy = (hv / C::HW) % C::HH, hz = hv / (C::HW * C::HH);
+        const int gz = z0 + ad - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = hv < C::HV && gz >= 0 && gz < Dl && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl;
+        hoff[i] = ok ? ((((long)n * Dl + gz) * Hl + gy) * Wl + gx) * Cin + 4 * q : 0;
+        hmask |= (unsigned)ok << i;
+    }
+    auto load_halo = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < C::NH; ++i) hreg[i] = *reinterpret_cast<const float4*>(x + hoff[i] + c0);
+    };
+    load_halo(0);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) {
+        bxr[i] = wlane[i * 256];
+        byr[i] = wlane[i * 256 + 128];
+    }
+    // pin the first loads: the loop is then entered with nothing in flight and the compiler counts,
+    // per wait, the younger loads that may stay outstanding (loads return in order)
+#define SIV_PIN(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
+#pragma unroll
+    for (int i = 0; i < C::NH; ++i) SIV_PIN(hreg[i]);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) { SIV_PIN(bxr[i]); SIV_PIN(byr[i]); }
+#undef SIV_PIN
+
+    for (int cc = 0; cc < nchunk; ++cc) {
+        __syncthreads();  // previous chunk's MFMAs are done with the halo
+#pragma unroll
+        for (int i = 0; i < C::NH; ++i) {
+            const int idx = tid + C::NTHR * i;
+            if (!((hmask >> i) & 1)) hreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((idx >> 1) < C::HV) {
+                uint2 ph, pm, pl;
+                split3(hreg[i], ph, pm, pl);
+                float* d = lds + (idx >> 1) * C::CKP + 2 * (idx & 1);
+                *reinterpret_cast<uint2*>(d) = ph;
+                *reinterpret_cast<uint2*>(d + 4) = pm;
+                *reinterpret_cast<uint2*>(d + 8) = pl;
+            }
+        }
+        __syncthreads();
+        load_halo((cc + 1 < nchunk ? cc + 1 : cc) * C::CK);
+        const uint4* wc = wlane + (long)cc * C::TAPS * 256;
+        bf16x8 n1, n2, n3;            // A operands, read one (tap, row tile) unit ahead of their MFMAs
+        n1 = *reinterpret_cast<const bf16x8*>(lds + aoff1[0]);
+        n2 = *reinterpret_cast<const bf16x8*>(lds + aoff2[0]);
+        n3 = *reinterpret_cast<const bf16x8*>(lds + aoff3[0]);
+#pragma unroll
+        for (int u = 0; u < C::TAPS * C::AM; ++u) {
+            const int t = u / C::AM, a = u % C::AM;
+            const int pos = t & 3;               // (H parity, W parity): the accumulator set
+            const bf16x8 a1 = n1, a2 = n2, a3 = n3;
+            const bf16x8 bx8 = __builtin_bit_cast(bf16x8, bxr[t % PD]);
+            const bf16x8 by8 = __builtin_bit_cast(bf16x8, byr[t % PD]);
+            if (u + 1 < C::TAPS * C::AM) {
+                const int t1 = (u + 1) / C::AM, a1i = (u + 1) % C::AM;
+                const int ah = (t1 >> 1) & 1, aw = t1 & 1, sd = t1 >> 4, sh = (t1 >> 3) & 1, sw = (t1 >> 2) & 1;
+                const int tapoff = ((sd * C::HH + ah + sh) * C::HW + aw + sw) * C::CKP;
+                n1 = *reinterpret_cast<const bf16x8*>(lds + aoff1[a1i] + tapoff);
+                n2 = *reinterpret_cast<const bf16x8*>(lds + aoff2[a1i] + tapoff);
+                n3 = *reinterpret_cast<const bf16x8*>(lds + aoff3[a1i] + tapoff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[pos][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, bx8, acc[pos][a], 0, 0, 0);   // al*bh | am*bm
+            acc[pos][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, by8, acc[pos][a], 0, 0, 0);   // am*bh | ah*bl
+            acc[pos][a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bx8, acc[pos][a], 0, 0, 0);   // ah*bh | ah*bm
+            __builtin_amdgcn_sched_barrier(0);
+            if (a == C::AM - 1) {
+                bxr[t % PD] = wc[(t + PD) * 256];
+                byr[t % PD] = wc[(t + PD) * 256 + 128];
+            }
+        }
+    }
+
+    // store: per row tile and parity class, transpose the 32x32 result through this wave's slice of
+    // LDS and write 16-byte channel runs.  When stat_part is given the block also emits, per output
+    // channel, the sum and the sum of squares of its (bias-free) outputs.
+    float* tile = lds + wave * C::EPI_FLOATS;
+    const int cq = lane & 7;
+    const int co = co0 + wn * 32 + 4 * cq;
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && co < Cout) bq = *reinterpret_cast<const float4*>(bias + co);
+    const int orig_b = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;     // this lane's column (channel co0 + wn*32 + li), its 16 rows per tile
+#pragma unroll
+    for (int a = 0; a < C::AM; ++a) {
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[pos][a][r];
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                tile[row * C::EPI_STRIDE + li] = v;
+                if (stat_part) {
+                    const int m = (wm * C::AM + a) * 32 + row;
+                    const int gz = z0 + m / (LBH * LBW), gy = y0 + (m / LBW) % LBH, gx = x0 + m % LBW;
+                    if (m < C::M && gz < Dl && gy < Hl && gx < Wl) {
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + (lane >> 3);
+                const int m = (wm * C::AM + a) * 32 + row;
+                const int gz = z0 + m / (LBH * LBW), gy = y0 + (m / LBW) % LBH, gx = x0 + m % LBW;
+                float4 v = *reinterpret_cast<const float4*>(tile + row * C::EPI_STRIDE + 4 * cq);
+                v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                if (m < C::M && gz < Dl && gy < Hl && gx < Wl && co < Cout) {
+                    const long o = (((long)n * D + 2 * gz + ad) * H + 2 * gy + (pos >> 1)) * W + 2 * gx + (pos & 1);
+                    *reinterpret_cast<float4*>(y + o * Cout + co) = v;
+                }
+            }
+        }
+    }
+    if (stat_part) {
+        s1 += __shfl_xor(s1, 32, 64);      // the two lane halves hold the same column
+        s2 += __shfl_xor(s2, 32, 64);
+        __syncthreads();
+        float* red = lds;                  // [2 (wm)][2 (sum, sumsq)][64 co]
+        if (lh == 0) {
+            red[(wm * 2 + 0) * 64 + wn * 32 + li] = s1;
+            red[(wm * 2 + 1) * 64 + wn * 32 + li] = s2;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int k = tid >> 6, c = tid & 63;
+            if (co0 + c < Cout)
+                stat_part[((long)orig_b * 2 + k) * Cout + co0 + c] = red[k * 64 + c] + red[(2 + k) * 64 + c];
+        }
+    }
+}
+
+// Packed, pre-summed weights as bf16 pieces: per (co tile, ad, ci chunk, tap) two operand slices of
+// [64 co][2 lane halves][8 ci]: slice 0 = (h | m), slice 1 = (h | l).
+__global__ __launch_bounds__(256) void k2_up_pack_weights_b3(const float* __restrict__ w,
+                                                             __bf16* __restrict__ wp, int Kin, int Kout) {
+    const int nchunk = Kin / 8, ntile = Kout / 64;
+    const long total = (long)ntile * 2 * nchunk * 32 * 2 * 64 * 2 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        long r = i >> 3;
+        const int half = (int)(r & 1); r >>= 1;
+        const int co = (int)(r & 63); r >>= 6;
+        const int which = (int)(r & 1); r >>= 1;
+        const int t = (int)(r & 31); r >>= 5;
+        const int cc = (int)(r % nchunk); r /= nchunk;
+        const int ad = (int)(r & 1);
+        const int ct = (int)(r >> 1);
+        const int aw = t & 1, ah = (t >> 1) & 1, sw = (t >> 2) & 1, sh = (t >> 3) & 1, sd = t >> 4;
+        const int kco = ct * 64 + co, kci = cc * 8 + j;
+        int d0, d1, h0, h1, w0, w1;
+        collapsed_range(ad, sd, d0, d1);
+        collapsed_range(ah, sh, h0, h1);
+        collapsed_range(aw, sw, w0, w1);
+        float v = 0.f;
+        for (int kd = d0; kd <= d1; ++kd)
+            for (int kh = h0; kh <= h1; ++kh)
+                for (int kw = w0; kw <= w1; ++kw) v += w[((long)kco * 27 + (kd * 3 + kh) * 3 + kw) * Kin + kci];
+        __bf16 h, m, l;
+        split3_scalar(v, h, m, l);
+        wp[i] = half == 0 ? h : (which == 0 ? m : l);
+    }
+}
+
 static bool up_wide10(int W) { return (W / 2) % 10 == 0 && (W / 2) % 8 != 0; }
 
 bool k2_up_fwd_supported(int Cin, int Cout) { return Cin % 8 == 0 && Cout % 64 == 0; }
 size_t k2_up_fwd_ws_bytes(int Cin, int Cout) {
-    return ((size_t)(Cout / 64) * 2 * (Cin / 8) * 32 * 512 + SIV_UPD * 512) * sizeof(float);
+    // sized for the split-bf16 packing (two 2 KB operand slices per tap), which is the larger one
+    return ((size_t)(Cout / 64) * 2 * (Cin / 8) * 32 + 4) * 4096;
 }
 // number of [2][Cout] partial-statistics rows the kernel emits (D, H, W: output extents)
 long k2_up_fwd_blocks(int N, int D, int H, int W) {
@@ -283,8 +520,8 @@ long k2_up_fwd_blocks(int N, int D, int H, int W) {
 }
 
 template <int LBD, int LBH, int LBW>
-static int up_launch_cfg(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H,
-                         int W, int Cin, int Cout, hipStream_t s, float* stat_part) {
+static int up_launch_cfg(const float* x, const void* wp, const float* bias, float* y, int N, int D, int H,
+                         int W, int Cin, int Cout, hipStream_t s, float* stat_part, bool split) {
     using C = UpCfg<LBD, LBH, LBW>;
     const int nbd = (int)cdiv(D / 2, LBD), nbh = (int)cdiv(H / 2, LBH), nbw = (int)cdiv(W / 2, LBW);
     const long nblk = (long)N * nbd * nbh * nbw * 2;
@@ -292,26 +529,38 @@ static int up_launch_cfg(const float* x, const float* wp, const float* bias, flo
         set_error("conv3d_k3(upsampled): too many bricks");
         return SIV_EINVAL;
     }
-    k2_up_fwd<LBD, LBH, LBW><<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 256, C::LDS_BYTES, s>>>(
-        x, wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part);
+    const dim3 grid((unsigned)nblk, (unsigned)(Cout / 64));
+    if (split)
+        k2_up_fwd_b3<LBD, LBH, LBW><<<grid, 256, C::LDS_BYTES, s>>>(x, (const uint4*)wp, bias, y, N, D, H, W, Cin,
+                                                                    Cout, nbd, nbh, nbw, stat_part);
+    else
+        k2_up_fwd<LBD, LBH, LBW><<<grid, 256, C::LDS_BYTES, s>>>(x, (const float*)wp, bias, y, N, D, H, W, Cin, Cout,
+                                                                 nbd, nbh, nbw, stat_part);
     SIV_CHECK_LAUNCH("conv3d_k3(upsampled)");
     return SIV_OK;
 }
 
 // x: [N][D/2][H/2][W/2][Cin] -> y: [N][D][H][W][Cout].  stat_part (optional): receives
 // [k2_up_fwd_blocks()][2][Cout] per-block sums / sums of squares of the bias-free output; it must not
-// overlap the first k2_up_fwd_ws_bytes() bytes of ws.
+// overlap the first k2_up_fwd_ws_bytes() bytes of ws.  split: products from bf16 pieces.
 int k2_up_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H,
-                     int W, int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t s, float* stat_part) {
+                     int W, int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t s, float* stat_part,
+                     bool split) {
     SIV_CHECK_WS(k2_up_fwd_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(upsampled)");
-    float* wp = (float*)ws;
-    const long total = (long)(Cout / 64) * 2 * (Cin / 8) * 32 * 512;
-    long g = cdiv(total, 256);
-    if (g > 4096) g = 4096;
-    k2_up_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout);
+    if (split) {
+        const long total = (long)(Cout / 64) * 2 * (Cin / 8) * 32 * 2 * 64 * 2 * 8;
+        long g = cdiv(total, 256);
+        if (g > 4096) g = 4096;
+        k2_up_pack_weights_b3<<<(unsigned)g, 256, 0, s>>>(w, (__bf16*)ws, Cin, Cout);
+    } else {
+        const long total = (long)(Cout / 64) * 2 * (Cin / 8) * 32 * 512;
+        long g = cdiv(total, 256);
+        if (g > 4096) g = 4096;
+        k2_up_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, (float*)ws, Cin, Cout);
+    }
     SIV_CHECK_LAUNCH("conv3d_k3(pack upsampled weights)");
-    if (up_wide10(W)) return up_launch_cfg<1, 12, 10>(x, wp, bias, y, N, D, H, W, Cin, Cout, s, stat_part);
-    return up_launch_cfg<2, 8, 8>(x, wp, bias, y, N, D, H, W, Cin, Cout, s, stat_part);
+    if (up_wide10(W)) return up_launch_cfg<1, 12, 10>(x, ws, bias, y, N, D, H, W, Cin, Cout, s, stat_part, split);
+    return up_launch_cfg<2, 8, 8>(x, ws, bias, y, N, D, H, W, Cin, Cout, s, stat_part, split);
 }
 
 // ---------------------------------------------------------------------------------

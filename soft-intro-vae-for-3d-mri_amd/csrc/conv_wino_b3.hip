@@ -18,13 +18,11 @@
 // operands (bh | bm) and (bh | bl).  Tiling, staging map, epilogue and statistics are those of
 // k3_fwd_wino<1>.  Inf inputs turn into NaN (inf - inf in the split), finite data are unaffected.
 #include "siv_common.h"
+#include "split_bf16.h"
 
 namespace siv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct B3Cfg {
     static constexpr int BD = 4, BH = 8, BW = 8;
@@ -38,29 +36,14 @@ struct B3Cfg {
     static constexpr int V_FLOATS = 4 * PLANE;
     static constexpr int TAPS = 36;
     static constexpr int TAP_Q = 256;                     // uint4 per tap: two operand slices of [64 co][2][8 ci]
-    static constexpr int PD = 3;                          // weight operands fetched 3 taps ahead
+#ifndef SIV_B3PD
+#define SIV_B3PD 3
+#endif
+    static constexpr int PD = SIV_B3PD;                   // weight operands fetched PD taps ahead
     static constexpr int EPI_STRIDE = 40, EPI_FLOATS = 32 * EPI_STRIDE;
     static constexpr int LDS_FLOATS = V_FLOATS > NW * EPI_FLOATS ? V_FLOATS : NW * EPI_FLOATS;
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
 };
-
-// round-to-nearest-even pair conversion (v_cvt_pk_bf16_f32): low half = a, high half = b
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-    const f32x2 v = {a, b};
-    const bf16x2 r = __builtin_convertvector(v, bf16x2);
-    return __builtin_bit_cast(unsigned, r);
-}
-__device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xFFFF0000u); }
-
-// four fp32 values -> three pieces of four bf16 each
-__device__ __forceinline__ void split3(float4 v, uint2& h, uint2& m, uint2& l) {
-    h.x = pk_bf16(v.x, v.y); h.y = pk_bf16(v.z, v.w);
-    const float rx = v.x - bf_lo(h.x), ry = v.y - bf_hi(h.x), rz = v.z - bf_lo(h.y), rw = v.w - bf_hi(h.y);
-    m.x = pk_bf16(rx, ry); m.y = pk_bf16(rz, rw);
-    l.x = pk_bf16(rx - bf_lo(m.x), ry - bf_hi(m.x));
-    l.y = pk_bf16(rz - bf_lo(m.y), rw - bf_hi(m.y));
-}
 
 __device__ __forceinline__ float4 q4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 q4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -305,10 +288,8 @@ __global__ __launch_bounds__(256) void k3_pack_weights_wino_b3(const float* __re
             g[kw] = flip ? w[((long)kci * 27 + (26 - tap)) * Kout + kco] : w[((long)kco * 27 + tap) * Kin + kci];
         }
         const float v = pos == 0 ? g[0] : pos == 1 ? 0.5f * ((g[0] + g[1]) + g[2]) : pos == 2 ? 0.5f * ((g[0] - g[1]) + g[2]) : g[2];
-        const __bf16 h = (__bf16)v;
-        const float r1 = v - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const __bf16 l = (__bf16)(r1 - (float)m);
+        __bf16 h, m, l;
+        split3_scalar(v, h, m, l);
         wp[i] = half == 0 ? h : (which == 0 ? m : l);
     }
 }

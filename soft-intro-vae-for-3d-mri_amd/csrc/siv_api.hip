@@ -1,6 +1,7 @@
 // C-ABI entry points that dispatch between the convolution kernel families, plus the
 // library-wide helpers (error string, version, workspace size, test overrides).
 #include "siv_common.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace siv {
@@ -15,7 +16,18 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-int conv_path() { return g_conv_path; }
+// Path 0 ("automatic") resolves to the value of the environment variable SIV_CONV_PATH when that is
+// set (e.g. SIV_CONV_PATH=5 runs a whole training job on the split-bf16 kernels), else to 0.
+int conv_path() {
+    if (g_conv_path != 0) return g_conv_path;
+    static int env_path = -1;
+    if (env_path < 0) {
+        const char* e = getenv("SIV_CONV_PATH");
+        const int v = e ? atoi(e) : 0;
+        env_path = (v >= 0 && v <= 5) ? v : 0;
+    }
+    return env_path;
+}
 
 // conv_generic.hip
 int k3_fwd_generic_launch(const float*, const float*, const float*, float*, int, int, int, int, int,
@@ -48,7 +60,7 @@ bool k2_up_fwd_supported(int Cin, int Cout);
 size_t k2_up_fwd_ws_bytes(int Cin, int Cout);
 long k2_up_fwd_blocks(int N, int D, int H, int W);
 int k2_up_fwd_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int, void*,
-                     size_t, hipStream_t, float*);
+                     size_t, hipStream_t, float*, bool);
 bool k2_up_dgrad_supported(int Cin, int Cout);
 int k2_up_dgrad_launch(const float*, const float*, float*, int, int, int, int, int, int, void*, size_t,
                        hipStream_t);
@@ -122,7 +134,7 @@ extern "C" int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bi
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
         return k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s);
     if (use_up(path, al, ups, Cin, Cout))
-        return k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, nullptr);
+        return k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, nullptr, path == 5);
     if (use_b3(path, al, ups, Cin, Cout))
         return k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, nullptr);
     if (use_wino(path, al, N, D, H, W, Cin, Cout))
@@ -153,7 +165,7 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
         const long nblk = k2_up_fwd_blocks(N, D, H, W);
         SIV_CHECK_WS(wbytes + (size_t)nblk * 2 * Cout * sizeof(float), ws_bytes, "conv3d_k3_fwd_bnstats");
         float* part = (float*)((char*)ws + wbytes);
-        rc = k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, part);
+        rc = k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, part, conv_path() == 5);
         if (rc) return rc;
         return bn_finalize_launch(bias, part, (int)nblk, M, Cout, mean, var, running_mean, running_var,
                                   num_batches_tracked, momentum, s);
