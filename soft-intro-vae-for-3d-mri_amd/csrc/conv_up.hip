@@ -826,9 +826,11 @@ struct UdCfg {
 };
 
 // dy: [N][D][H][W][Cout] (D, H, W even); dx: [N][D/2][H/2][W/2][Cin]; wp: see k2_up_pack_dgrad.
-template <int LBD, int LBH, int LBW>
+// SPLIT: every fp32 product formed from three bf16 pieces per operand on the bf16 matrix cores (scheme
+// and operand packing: conv_wino_b3.hip); the staged dy voxels then hold [h | m | l] pieces of 8 channels.
+template <int LBD, int LBH, int LBW, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ dy,
-                                                      const float* __restrict__ wp,
+                                                      const void* __restrict__ wpv,
                                                       float* __restrict__ dx, int N, int D, int H, int W,
                                                       int Cin, int Cout, int nbd, int nbh, int nbw) {
     using C = UdCfg<LBD, LBH, LBW>;
@@ -856,18 +858,25 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-    // LDS offset of this lane's A row for tap (u_h, u_w) = (-1, -1)
-    int aoff[C::AM];
+    // LDS offset of this lane's A row for tap (u_h, u_w) = (-1, -1); with SPLIT three of them, one per
+    // A operand (pieces h|h, m|h, l|m by lane half)
+    int aoff[C::AM], aoff2[C::AM], aoff3[C::AM];
 #pragma unroll
     for (int a = 0; a < C::AM; ++a) {
         int m = (wm * C::AM + a) * 32 + li;
         if (m >= C::M) m = 0;                   // padding row: reads a valid voxel, never stored
         const int dz = m / (LBH * LBW), dyy = (m / LBW) % LBH, dxx = m % LBW;
-        aoff[a] = (dz * C::HH + 2 * dyy) * C::PITCH + dxx * C::CKP + 4 * lh;
+        const int row = (dz * C::HH + 2 * dyy) * C::PITCH + dxx * C::CKP;
+        aoff[a] = SPLIT ? row : row + 4 * lh;
+        aoff2[a] = row + (lh ? 0 : 4);
+        aoff3[a] = row + (lh ? 4 : 8);
     }
-    const float* wlane = wp + (long)blockIdx.y * nstep * C::TAPS * C::SLICE + (wn * 32 + li) * 8 + 4 * lh;
     constexpr int PD = 4;
+    // fp32: one [64 ci][8 co] slice per tap; SPLIT: two operand slices of [64 ci][2 lane halves][8 co] bf16
+    const float* wlane = (const float*)wpv + (long)blockIdx.y * nstep * C::TAPS * C::SLICE + (wn * 32 + li) * 8 + 4 * lh;
+    const uint4* wlq = (const uint4*)wpv + (long)blockIdx.y * nstep * C::TAPS * 256 + (wn * 32 + li) * 2 + lh;
     float4 bring[PD];
+    uint4 bxr[PD], byr[PD];
 
     // staging: item = (dy voxel of the staged planes, channel half).  Offsets are relative to the
     // brick's first voxel in plane 2*z0 (always inside the tensor); the plane parity u is added per step.
@@ -886,7 +895,7 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
         const bool ok = hv < C::HV && gy >= 0 && gy < H && gx >= 0 && gx < W;
         hoff[i] = ok ? ((2 * pz * H + (hy - 1)) * W + (hx - 1)) * Cout + 4 * q : 0;
         hpz[i] = ok ? 2 * (z0 + pz) : -4;       // high-resolution plane for u = 0 (-4: never valid)
-        hdst[i] = (pz * C::HH + hy) * C::PITCH + ((hx & 1) * C::HWH + (hx >> 1)) * C::CKP + 4 * q;
+        hdst[i] = (pz * C::HH + hy) * C::PITCH + ((hx & 1) * C::HWH + (hx >> 1)) * C::CKP + (SPLIT ? 2 : 4) * q;
         hmask |= (unsigned)(hv < C::HV) << i;
     }
     auto load_halo = [&](int step) {
@@ -903,13 +912,22 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
         return mk;
     };
     unsigned nextmask = load_halo(0);
-#pragma unroll
-    for (int i = 0; i < PD; ++i) bring[i] = *reinterpret_cast<const float4*>(wlane + i * C::SLICE);
 #define SIV_PIN(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
+#pragma unroll
+    for (int i = 0; i < PD; ++i) {
+        if constexpr (SPLIT) {
+            bxr[i] = wlq[i * 256];
+            byr[i] = wlq[i * 256 + 128];
+        } else {
+            bring[i] = *reinterpret_cast<const float4*>(wlane + i * C::SLICE);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < C::NH; ++i) SIV_PIN(hreg[i]);
 #pragma unroll
-    for (int i = 0; i < PD; ++i) SIV_PIN(bring[i]);
+    for (int i = 0; i < PD; ++i) {
+        if constexpr (SPLIT) { SIV_PIN(bxr[i]); SIV_PIN(byr[i]); } else { SIV_PIN(bring[i]); }
+    }
 #undef SIV_PIN
 
     for (int step = 0; step < nstep; ++step) {
@@ -918,10 +936,53 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
 #pragma unroll
         for (int i = 0; i < C::NH; ++i) {
             if (!((curmask >> i) & 1)) hreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((hmask >> i) & 1) *reinterpret_cast<float4*>(lds + hdst[i]) = hreg[i];
+            if ((hmask >> i) & 1) {
+                if constexpr (SPLIT) {
+                    uint2 ph, pm, pl;
+                    split3(hreg[i], ph, pm, pl);
+                    float* d = lds + hdst[i];          // hdst carries 2 * q here
+                    *reinterpret_cast<uint2*>(d) = ph;
+                    *reinterpret_cast<uint2*>(d + 4) = pm;
+                    *reinterpret_cast<uint2*>(d + 8) = pl;
+                } else {
+                    *reinterpret_cast<float4*>(lds + hdst[i]) = hreg[i];
+                }
+            }
         }
         __syncthreads();
         nextmask = load_halo(step + 1 < nstep ? step + 1 : step);
+        if constexpr (SPLIT) {
+            const uint4* wq = wlq + (long)step * C::TAPS * 256;
+            bf16x8 n1, n2, n3;            // A operands, read one (tap, row tile) unit ahead of their MFMAs
+            n1 = *reinterpret_cast<const bf16x8*>(lds + aoff[0]);
+            n2 = *reinterpret_cast<const bf16x8*>(lds + aoff2[0]);
+            n3 = *reinterpret_cast<const bf16x8*>(lds + aoff3[0]);
+#pragma unroll
+            for (int u = 0; u < C::TAPS * C::AM; ++u) {
+                const int t = u / C::AM, a = u % C::AM;
+                const bf16x8 a1 = n1, a2 = n2, a3 = n3;
+                const bf16x8 bx8 = __builtin_bit_cast(bf16x8, bxr[t % PD]);
+                const bf16x8 by8 = __builtin_bit_cast(bf16x8, byr[t % PD]);
+                if (u + 1 < C::TAPS * C::AM) {
+                    const int t1 = (u + 1) / C::AM, a1i = (u + 1) % C::AM;
+                    const int uh = t1 >> 2, uw = t1 & 3;
+                    const int tapoff = uh * C::PITCH + ((uw & 1) * C::HWH + (uw >> 1)) * C::CKP;
+                    n1 = *reinterpret_cast<const bf16x8*>(lds + aoff[a1i] + tapoff);
+                    n2 = *reinterpret_cast<const bf16x8*>(lds + aoff2[a1i] + tapoff);
+                    n3 = *reinterpret_cast<const bf16x8*>(lds + aoff3[a1i] + tapoff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, bx8, acc[a], 0, 0, 0);   // al*bh | am*bm
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, by8, acc[a], 0, 0, 0);   // am*bh | ah*bl
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bx8, acc[a], 0, 0, 0);   // ah*bh | ah*bm
+                __builtin_amdgcn_sched_barrier(0);
+                if (a == C::AM - 1) {
+                    bxr[t % PD] = wq[(t + PD) * 256];
+                    byr[t % PD] = wq[(t + PD) * 256 + 128];
+                }
+            }
+            continue;
+        }
         const float* wc = wlane + (long)step * C::TAPS * C::SLICE;
         float4 anext[C::AM];
 #pragma unroll
@@ -1006,13 +1067,45 @@ __global__ __launch_bounds__(256) void k2_up_pack_dgrad(const float* __restrict_
     }
 }
 
-bool k2_up_dgrad_supported(int Cin, int Cout) { return Cout % 8 == 0 && Cin % 64 == 0; }
-size_t k2_up_dgrad_ws_bytes(int Cin, int Cout) {
-    return ((size_t)(Cin / 64) * (Cout / 8) * 64 * 512 + 4 * 512) * sizeof(float);
+// The same kernel as bf16 pieces: per (ci tile, co chunk, ud, tap) two operand slices of
+// [64 ci][2 lane halves][8 co]: slice 0 = (h | m), slice 1 = (h | l).
+__global__ __launch_bounds__(256) void k2_up_pack_dgrad_b3(const float* __restrict__ w, __bf16* __restrict__ wp,
+                                                           int Kin, int Kout) {
+    const int nchunk = Kout / 8, ntile = Kin / 64;
+    const long total = (long)ntile * nchunk * 64 * 2 * 64 * 2 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        long r = i >> 3;
+        const int half = (int)(r & 1); r >>= 1;
+        const int ci = (int)(r & 63); r >>= 6;
+        const int which = (int)(r & 1); r >>= 1;
+        const int t = (int)(r & 15); r >>= 4;
+        const int ud = (int)(r & 3); r >>= 2;
+        const int cc = (int)(r % nchunk);
+        const int ct = (int)(r / nchunk);
+        const int uh = t >> 2, uw = t & 3;
+        const int kci = ct * 64 + ci, kco = cc * 8 + j;
+        const int d0 = ud == 0 ? 2 : ud == 1 ? 1 : 0, d1 = ud <= 1 ? 2 : ud == 2 ? 1 : 0;
+        const int h0 = uh == 0 ? 2 : uh == 1 ? 1 : 0, h1 = uh <= 1 ? 2 : uh == 2 ? 1 : 0;
+        const int w0 = uw == 0 ? 2 : uw == 1 ? 1 : 0, w1 = uw <= 1 ? 2 : uw == 2 ? 1 : 0;
+        float v = 0.f;
+        for (int kd = d0; kd <= d1; ++kd)
+            for (int kh = h0; kh <= h1; ++kh)
+                for (int kw = w0; kw <= w1; ++kw) v += w[((long)kco * 27 + (kd * 3 + kh) * 3 + kw) * Kin + kci];
+        __bf16 h, m, l;
+        split3_scalar(v, h, m, l);
+        wp[i] = half == 0 ? h : (which == 0 ? m : l);
+    }
 }
 
-template <int LBD, int LBH, int LBW>
-static int up_dgrad_cfg(const float* dy, const float* wp, float* dx, int N, int D, int H, int W, int Cin,
+bool k2_up_dgrad_supported(int Cin, int Cout) { return Cout % 8 == 0 && Cin % 64 == 0; }
+size_t k2_up_dgrad_ws_bytes(int Cin, int Cout) {   // sized for the split-bf16 packing (4 KB per tap)
+    return ((size_t)(Cin / 64) * (Cout / 8) * 64 + 4) * 4096;
+}
+
+template <int LBD, int LBH, int LBW, bool SPLIT>
+static int up_dgrad_cfg(const float* dy, const void* wp, float* dx, int N, int D, int H, int W, int Cin,
                         int Cout, hipStream_t s) {
     using C = UdCfg<LBD, LBH, LBW>;
     const int nbd = (int)cdiv(D / 2, LBD), nbh = (int)cdiv(H / 2, LBH), nbw = (int)cdiv(W / 2, LBW);
@@ -1022,29 +1115,40 @@ static int up_dgrad_cfg(const float* dy, const float* wp, float* dx, int N, int 
         return SIV_EINVAL;
     }
     // more than 64 KB of dynamic LDS is an opt-in
-    if (hipFuncSetAttribute((const void*)k2_up_dgrad<LBD, LBH, LBW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)k2_up_dgrad<LBD, LBH, LBW, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)C::LDS_BYTES) != hipSuccess) {
         set_error("conv3d_k3_dgrad(upsampled): cannot reserve %zu bytes of LDS", C::LDS_BYTES);
         return SIV_EHIP;
     }
-    k2_up_dgrad<LBD, LBH, LBW><<<dim3((unsigned)nblk, (unsigned)(Cin / 64)), 256, C::LDS_BYTES, s>>>(
+    k2_up_dgrad<LBD, LBH, LBW, SPLIT><<<dim3((unsigned)nblk, (unsigned)(Cin / 64)), 256, C::LDS_BYTES, s>>>(
         dy, wp, dx, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
     SIV_CHECK_LAUNCH("conv3d_k3_dgrad(upsampled)");
     return SIV_OK;
 }
 
-// dy: [N][D][H][W][Cout] -> dx: [N][D/2][H/2][W/2][Cin]; w: the convolution's weights [Cout][27][Cin]
+// dy: [N][D][H][W][Cout] -> dx: [N][D/2][H/2][W/2][Cin]; w: the convolution's weights [Cout][27][Cin].
+// split: products from bf16 pieces.
 int k2_up_dgrad_launch(const float* dy, const float* w, float* dx, int N, int D, int H, int W, int Cin,
-                       int Cout, void* ws, size_t ws_bytes, hipStream_t s) {
+                       int Cout, void* ws, size_t ws_bytes, hipStream_t s, bool split) {
     SIV_CHECK_WS(k2_up_dgrad_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3_dgrad(upsampled)");
-    float* wp = (float*)ws;
-    const long total = (long)(Cin / 64) * (Cout / 8) * 64 * 512;
-    long g = cdiv(total, 256);
-    if (g > 4096) g = 4096;
-    k2_up_pack_dgrad<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout);
+    if (split) {
+        const long total = (long)(Cin / 64) * (Cout / 8) * 64 * 2 * 64 * 2 * 8;
+        long g = cdiv(total, 256);
+        if (g > 4096) g = 4096;
+        k2_up_pack_dgrad_b3<<<(unsigned)g, 256, 0, s>>>(w, (__bf16*)ws, Cin, Cout);
+    } else {
+        const long total = (long)(Cin / 64) * (Cout / 8) * 64 * 512;
+        long g = cdiv(total, 256);
+        if (g > 4096) g = 4096;
+        k2_up_pack_dgrad<<<(unsigned)g, 256, 0, s>>>(w, (float*)ws, Cin, Cout);
+    }
     SIV_CHECK_LAUNCH("conv3d_k3_dgrad(pack upsampled weights)");
-    if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10>(dy, wp, dx, N, D, H, W, Cin, Cout, s);
-    return up_dgrad_cfg<4, 8, 8>(dy, wp, dx, N, D, H, W, Cin, Cout, s);
+    if (split) {
+        if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, true>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
+        return up_dgrad_cfg<4, 8, 8, true>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
+    }
+    if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, false>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
+    return up_dgrad_cfg<4, 8, 8, false>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
 }
 
 }  // namespace siv
