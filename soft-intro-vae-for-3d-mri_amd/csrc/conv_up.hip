@@ -43,6 +43,78 @@ struct UpCfg {
     static_assert(M <= 128 && M > 96, "two row tiles per wave, two waves along M");
 };
 
+// Epilogue shared by the two forward kernels: per row tile and parity class, transpose the 32x32 result
+// through this wave's slice of LDS and write 16-byte channel runs.  When stat_part is given the block also
+// emits, per output channel, the sum and the sum of squares of its (bias-free) outputs.
+template <int LBD, int LBH, int LBW>
+__device__ __forceinline__ void up_fwd_store(f32x16 (&acc)[4][2], float* lds, const float* __restrict__ bias,
+                                             float* __restrict__ y, float* __restrict__ stat_part, int n, int z0,
+                                             int y0, int x0, int ad, int co0, int D, int H, int W, int Cout) {
+    using C = UpCfg<LBD, LBH, LBW>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
+    float* tile = lds + wave * C::EPI_FLOATS;
+    const int cq = lane & 7;
+    const int co = co0 + wn * 32 + 4 * cq;
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && co < Cout) bq = *reinterpret_cast<const float4*>(bias + co);
+    const int orig_b = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;     // this lane's column (channel co0 + wn*32 + li), its 16 rows per tile
+#pragma unroll
+    for (int a = 0; a < C::AM; ++a) {
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[pos][a][r];
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                tile[row * C::EPI_STRIDE + li] = v;
+                if (stat_part) {
+                    const int m = (wm * C::AM + a) * 32 + row;
+                    const int gz = z0 + m / (LBH * LBW), gy = y0 + (m / LBW) % LBH, gx = x0 + m % LBW;
+                    if (m < C::M && gz < Dl && gy < Hl && gx < Wl) {
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + (lane >> 3);
+                const int m = (wm * C::AM + a) * 32 + row;
+                const int gz = z0 + m / (LBH * LBW), gy = y0 + (m / LBW) % LBH, gx = x0 + m % LBW;
+                float4 v = *reinterpret_cast<const float4*>(tile + row * C::EPI_STRIDE + 4 * cq);
+                v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
+                if (m < C::M && gz < Dl && gy < Hl && gx < Wl && co < Cout) {
+                    const long o = (((long)n * D + 2 * gz + ad) * H + 2 * gy + (pos >> 1)) * W + 2 * gx + (pos & 1);
+                    *reinterpret_cast<float4*>(y + o * Cout + co) = v;
+                }
+            }
+        }
+    }
+    if (stat_part) {
+        s1 += __shfl_xor(s1, 32, 64);      // the two lane halves hold the same column
+        s2 += __shfl_xor(s2, 32, 64);
+        __syncthreads();
+        float* red = lds;                  // [2 (wm)][2 (sum, sumsq)][64 co]
+        if (lh == 0) {
+            red[(wm * 2 + 0) * 64 + wn * 32 + li] = s1;
+            red[(wm * 2 + 1) * 64 + wn * 32 + li] = s2;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int k = tid >> 6, c = tid & 63;
+            if (co0 + c < Cout)
+                stat_part[((long)orig_b * 2 + k) * Cout + co0 + c] = red[k * 64 + c] + red[(2 + k) * 64 + c];
+        }
+    }
+}
+
 // x: [N][D/2][H/2][W/2][Cin]; y: [N][D][H][W][Cout]; D, H, W even.  wp: see k2_up_pack_weights.
 template <int LBD, int LBH, int LBW>
 __global__ __launch_bounds__(256, 2) void k2_up_fwd(const float* __restrict__ x,
@@ -171,66 +243,7 @@ __global__ __launch_bounds__(256, 2) void k2_up_fwd(const float* __restrict__ x,
         }
     }
 
-    // store: per row tile and parity class, transpose the 32x32 result through this wave's slice of
-    // LDS and write 16-byte channel runs.  When stat_part is given the block also emits, per output
-    // channel, the sum and the sum of squares of its (bias-free) outputs.
-    float* tile = lds + wave * C::EPI_FLOATS;
-    const int cq = lane & 7;
-    const int co = co0 + wn * 32 + 4 * cq;
-    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias && co < Cout) bq = *reinterpret_cast<const float4*>(bias + co);
-    const int orig_b = blockIdx.x;
-    float s1 = 0.f, s2 = 0.f;     // this lane's column (channel co0 + wn*32 + li), its 16 rows per tile
-#pragma unroll
-    for (int a = 0; a < C::AM; ++a) {
-#pragma unroll
-        for (int pos = 0; pos < 4; ++pos) {
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[pos][a][r];
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                tile[row * C::EPI_STRIDE + li] = v;
-                if (stat_part) {
-                    const int m = (wm * C::AM + a) * 32 + row;
-                    const int gz = z0 + m / (LBH * LBW), gy = y0 + (m / LBW) % LBH, gx = x0 + m % LBW;
-                    if (m < C::M && gz < Dl && gy < Hl && gx < Wl) {
-                        s1 += v;
-                        s2 = fmaf(v, v, s2);
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const int row = ps * 8 + (lane >> 3);
-                const int m = (wm * C::AM + a) * 32 + row;
-                const int gz = z0 + m / (LBH * LBW), gy = y0 + (m / LBW) % LBH, gx = x0 + m % LBW;
-                float4 v = *reinterpret_cast<const float4*>(tile + row * C::EPI_STRIDE + 4 * cq);
-                v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
-                if (m < C::M && gz < Dl && gy < Hl && gx < Wl && co < Cout) {
-                    const long o = (((long)n * D + 2 * gz + ad) * H + 2 * gy + (pos >> 1)) * W + 2 * gx + (pos & 1);
-                    *reinterpret_cast<float4*>(y + o * Cout + co) = v;
-                }
-            }
-        }
-    }
-    if (stat_part) {
-        s1 += __shfl_xor(s1, 32, 64);      // the two lane halves hold the same column
-        s2 += __shfl_xor(s2, 32, 64);
-        __syncthreads();
-        float* red = lds;                  // [2 (wm)][2 (sum, sumsq)][64 co]
-        if (lh == 0) {
-            red[(wm * 2 + 0) * 64 + wn * 32 + li] = s1;
-            red[(wm * 2 + 1) * 64 + wn * 32 + li] = s2;
-        }
-        __syncthreads();
-        if (tid < 128) {
-            const int k = tid >> 6, c = tid & 63;
-            if (co0 + c < Cout)
-                stat_part[((long)orig_b * 2 + k) * Cout + co0 + c] = red[k * 64 + c] + red[(2 + k) * 64 + c];
-        }
-    }
+    up_fwd_store<LBD, LBH, LBW>(acc, lds, bias, y, stat_part, n, z0, y0, x0, ad, co0, D, H, W, Cout);
 }
 
 // Along one axis, the original taps k that collapse onto source s (0/1) for output parity a:
@@ -411,66 +424,7 @@ __global__ __launch_bounds__(256, 2) void k2_up_fwd_b3(const float* __restrict__
         }
     }
 
-    // store: per row tile and parity class, transpose the 32x32 result through this wave's slice of
-    // LDS and write 16-byte channel runs.  When stat_part is given the block also emits, per output
-    // channel, the sum and the sum of squares of its (bias-free) outputs.
-    float* tile = lds + wave * C::EPI_FLOATS;
-    const int cq = lane & 7;
-    const int co = co0 + wn * 32 + 4 * cq;
-    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias && co < Cout) bq = *reinterpret_cast<const float4*>(bias + co);
-    const int orig_b = blockIdx.x;
-    float s1 = 0.f, s2 = 0.f;     // this lane's column (channel co0 + wn*32 + li), its 16 rows per tile
-#pragma unroll
-    for (int a = 0; a < C::AM; ++a) {
-#pragma unroll
-        for (int pos = 0; pos < 4; ++pos) {
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[pos][a][r];
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                tile[row * C::EPI_STRIDE + li] = v;
-                if (stat_part) {
-                    const int m = (wm * C::AM + a) * 32 + row;
-                    const int gz = z0 + m / (LBH * LBW), gy = y0 + (m / LBW) % LBH, gx = x0 + m % LBW;
-                    if (m < C::M && gz < Dl && gy < Hl && gx < Wl) {
-                        s1 += v;
-                        s2 = fmaf(v, v, s2);
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const int row = ps * 8 + (lane >> 3);
-                const int m = (wm * C::AM + a) * 32 + row;
-                const int gz = z0 + m / (LBH * LBW), gy = y0 + (m / LBW) % LBH, gx = x0 + m % LBW;
-                float4 v = *reinterpret_cast<const float4*>(tile + row * C::EPI_STRIDE + 4 * cq);
-                v.x += bq.x; v.y += bq.y; v.z += bq.z; v.w += bq.w;
-                if (m < C::M && gz < Dl && gy < Hl && gx < Wl && co < Cout) {
-                    const long o = (((long)n * D + 2 * gz + ad) * H + 2 * gy + (pos >> 1)) * W + 2 * gx + (pos & 1);
-                    *reinterpret_cast<float4*>(y + o * Cout + co) = v;
-                }
-            }
-        }
-    }
-    if (stat_part) {
-        s1 += __shfl_xor(s1, 32, 64);      // the two lane halves hold the same column
-        s2 += __shfl_xor(s2, 32, 64);
-        __syncthreads();
-        float* red = lds;                  // [2 (wm)][2 (sum, sumsq)][64 co]
-        if (lh == 0) {
-            red[(wm * 2 + 0) * 64 + wn * 32 + li] = s1;
-            red[(wm * 2 + 1) * 64 + wn * 32 + li] = s2;
-        }
-        __syncthreads();
-        if (tid < 128) {
-            const int k = tid >> 6, c = tid & 63;
-            if (co0 + c < Cout)
-                stat_part[((long)orig_b * 2 + k) * Cout + co0 + c] = red[k * 64 + c] + red[(2 + k) * 64 + c];
-        }
-    }
+    up_fwd_store<LBD, LBH, LBW>(acc, lds, bias, y, stat_part, n, z0, y0, x0, ad, co0, D, H, W, Cout);
 }
 
 // Packed, pre-summed weights as bf16 pieces: per (co tile, ad, ci chunk, tap) two operand slices of
