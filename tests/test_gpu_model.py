@@ -212,6 +212,42 @@ def test_wide_model_step_matches_oracle():
             check(v, sd[k], k, tol=1e-4, floor=5e-4 if k.endswith("blocks.0.1.running_mean") else 1e-5)
 
 
+def test_split_bf16_path_step_matches_fp32_path():
+    """Conv path 5 (fp32 products formed from bf16 triples on the bf16 matrix cores) against the
+    exact-fp32 kernels of the same structure (path 3: Winograd wherever supported) through one full
+    E+D iteration of a 64-128 channel model: every loss term to 1e-5 relative, gradient norms per
+    parameter to 2 % (single gradient elements are LeakyReLU-sign-flip noise at this size for ANY
+    change of rounding, the two fp32 kernels included)."""
+    import siv.backend as sb
+    import siv.models.models as models
+    dims, Bn = (16, 24, 16), 2
+    gen = torch.Generator().manual_seed(16)
+    real = torch.rand(Bn, 1, *dims, generator=gen)
+    noise = torch.randn(Bn, 1, 4, 6, 4, generator=gen)
+    hp = O.Hyper(dims=dims)
+    res = {}
+    for path in (3, 5):
+        torch.manual_seed(15)
+        net = models.SoftIntroVAE(*WIDE)
+        with torch.no_grad():
+            for m in net.modules():
+                if type(m) == torch.nn.Conv3d:
+                    torch.nn.init.kaiming_normal_(m.weight, nonlinearity="leaky_relu")
+        net = net.to("cuda").train()
+        sb.get_backend().set_conv_path(path)
+        try:
+            (st, grads), = _run_steps(net, lambda s: (real, noise), hp, O.Draws(seed=23), 1)
+        finally:
+            sb.get_backend().set_conv_path(0)
+        res[path] = (st, grads)
+    for k in ("lossE", "lossD", "kl_real", "fake_kl", "rec_kl", "loss_rec"):
+        np.testing.assert_allclose(res[5][0][k], res[3][0][k], rtol=1e-5, err_msg=k)
+    for k, g3 in res[3][1].items():
+        if k.endswith(BN_CANCELLED) or float(g3.norm()) == 0.0:
+            continue
+        np.testing.assert_allclose(float(res[5][1][k].norm()), float(g3.norm()), rtol=2e-2, err_msg=k)
+
+
 def test_eval_forward_wide_matches_oracle():
     import siv.models.models as models
     torch.manual_seed(8)
