@@ -1,0 +1,335 @@
+// 3x3x3 convolution, forward / input gradient, with the Winograd F(2x2, 3x3) minimal-filtering
+// identity applied over (H, W) and the fp32 matrix cores doing the channel contraction.
+//
+// A 2x2 output tile of one z-plane depends on a 4x4 input patch of each of the three planes kd:
+//   Y = A^T [ sum_kd (G g_kd G^T) .* (B^T d_kd B) ] A
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1]
+// i.e. 16 positions x 3 planes = 48 multiply-adds per 4 outputs and channel pair: 12 per output
+// instead of the 27 of the direct kernel or the 18 of the one-dimensional F(2,3) kernel.  Everything
+// stays fp32; only the additions of the transforms change the rounding (the factors 1/2, 1/4 are exact).
+//
+//   M rows  = 2x2 output tiles of a 4x8x8-voxel brick (64 tiles = 2 row tiles), N = 64 output channels
+//   K       = 3 planes x Cin per position; 16 positions = 16 independent accumulator sets
+//   a block = 8 waves: wave (ph, wn) owns the four positions (ph, 0..3) of both row tiles for output
+//             channel half wn (8 accumulators = 128 registers)
+//
+// The transformed input V[pos][plane][tile][ci] of one 8-channel chunk takes 72 KB of LDS, so one block
+// runs per CU and nothing else would cover its barriers: V is double buffered.  While the waves multiply
+// chunk c out of one buffer, six of the eight waves fetch the 4x4 patches of chunk c+1 from global memory
+// into registers (overlapping patches: L1/L2 hits), transform them and fill the other buffer; one barrier
+// per chunk.  The output transform along W is done on the accumulators, the one along H needs the four
+// waves ph = 0..3 and goes through LDS together with the transposition for 16-byte stores.
+#include "siv_common.h"
+
+namespace siv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct W2Cfg {
+    static constexpr int BD = 4, BH = 8, BW = 8;
+    static constexpr int CK = 8, CKP = 12;
+    static constexpr int TPP = 16;                         // 4x4 tiles per plane
+    static constexpr int HD = BD + 2;                      // planes incl. halo
+    static constexpr int PLANE = HD * TPP * CKP;           // floats of one position: 1152
+    static constexpr int V_FLOATS = 16 * PLANE;            // 18432 floats = 72 KB
+    static constexpr int NTHR = 512, NT = 64;
+    static constexpr int TAPS = 48, SLICE = NT * 8;        // (kd, ph, pw) slices of [64 co][8 ci]
+    static constexpr int PD = 4;                           // weight fragments fetched 4 taps ahead
+    static constexpr int EPI_STRIDE = 40, EPI_TILE = 32 * EPI_STRIDE;
+    static constexpr int LDS_FLOATS = 2 * V_FLOATS;
+    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+    static_assert(16 * EPI_TILE <= LDS_FLOATS, "epilogue tiles fit");
+};
+
+__device__ __forceinline__ float4 w2sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 w2add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float2 w2sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 w2add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+
+__global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict__ x,
+                                                        const float* __restrict__ wp,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ y, int N, int D, int H, int W,
+                                                        int Cin, int Cout, int nbd, int nbh, int nbw,
+                                                        float* __restrict__ stat_part) {
+    using C = W2Cfg;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ph = wave & 3, wn = wave >> 2;
+
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    const int bx = b % nbw; b /= nbw;
+    const int by = b % nbh; b /= nbh;
+    const int bz = b % nbd;
+    const int n = b / nbd;
+    const int z0 = bz * C::BD, y0 = by * C::BH, x0 = bx * C::BW;
+    const int co0 = blockIdx.y * C::NT;
+    const int nchunk = Cin / C::CK;
+
+    f32x16 acc[4][2];          // [pw][row tile]
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][a][r] = 0.f;
+
+    // A row m = a*32 + li is tile (dz = m >> 4, th, tw): its V offset is linear in li
+    const int aoff0 = ph * 4 * C::PLANE + li * C::CKP + 4 * lh;       // + a*384 + kd*192 + pw*PLANE
+    // this lane's B fragment inside a packed [64 co][8 ci] slice; slices of this wave: kd*16 + ph*4 + pw
+    const float* wlane = wp + ((long)blockIdx.y * nchunk * C::TAPS + ph * 4) * C::SLICE + (wn * 32 + li) * 8 + 4 * lh;
+    constexpr int PD = C::PD;
+    float4 bring[PD];
+
+    // staging item of this lane: (tile-row r of the 6 x 16 tiles, channel pair q of the 8-channel chunk);
+    // the 384 items are the lanes of waves 0..5.  (Two channels per item, not four: the 16-voxel patch
+    // then takes 32 registers beside the 128 accumulators instead of 64.)
+    const bool s_on = wave < 6;
+    const int s_item = s_on ? wave * 64 + lane : 0;
+    const int s_q = s_item & 3, s_r = s_item >> 2;
+    const int s_hz = s_r >> 4, s_th = (s_r >> 2) & 3, s_tw = s_r & 3;
+    unsigned pmask = 0;        // validity of the 16 patch voxels
+    const int pgz = z0 - 1 + s_hz, pgy = y0 - 1 + 2 * s_th, pgx = x0 - 1 + 2 * s_tw;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool ok = s_on && pgz >= 0 && pgz < D && pgy + rr >= 0 && pgy + rr < H && pgx + c >= 0 && pgx + c < W;
+            pmask |= (unsigned)ok << (rr * 4 + c);
+        }
+    const float* xs = x + (long)n * D * H * W * Cin + 2 * s_q;       // this sample, this channel pair
+    const int pvox = (pgz * H + pgy) * W + pgx;                       // may lie outside; masked per voxel
+    float2 patch[16];
+    auto load_patch = [&](int c0) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = rr * 4 + c;
+                const int vox = ((pmask >> k) & 1) ? pvox + rr * W + c : 0;      // out of volume: reads voxel 0
+                patch[k] = *reinterpret_cast<const float2*>(xs + (long)vox * Cin + c0);
+            }
+    };
+    // The transform is cut into eight pieces that the multiply loop issues between the MFMA groups of
+    // eight consecutive taps, so that the matrix pipe never waits for a block of vector instructions:
+    // pieces 0..3 transform patch row 0..3 along W in place, pieces 4..7 finish column pw = 0..3 along H
+    // and write its four positions.
+    auto stage_piece = [&](int piece, float* buf) {
+        if (piece < 4) {
+            const int rr = piece;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (!((pmask >> (rr * 4 + c)) & 1)) patch[rr * 4 + c] = make_float2(0.f, 0.f);
+            const float2 t0 = w2sub(patch[rr * 4 + 0], patch[rr * 4 + 2]);
+            const float2 t1 = w2add(patch[rr * 4 + 1], patch[rr * 4 + 2]);
+            const float2 t2 = w2sub(patch[rr * 4 + 2], patch[rr * 4 + 1]);
+            const float2 t3 = w2sub(patch[rr * 4 + 1], patch[rr * 4 + 3]);
+            patch[rr * 4 + 0] = t0; patch[rr * 4 + 1] = t1; patch[rr * 4 + 2] = t2; patch[rr * 4 + 3] = t3;
+        } else {
+            const int pw = piece - 4;
+            float* dst = buf + s_r * C::CKP + 2 * s_q + pw * C::PLANE;
+            *reinterpret_cast<float2*>(dst + 0 * 4 * C::PLANE) = w2sub(patch[0 * 4 + pw], patch[2 * 4 + pw]);
+            *reinterpret_cast<float2*>(dst + 1 * 4 * C::PLANE) = w2add(patch[1 * 4 + pw], patch[2 * 4 + pw]);
+            *reinterpret_cast<float2*>(dst + 2 * 4 * C::PLANE) = w2sub(patch[2 * 4 + pw], patch[1 * 4 + pw]);
+            *reinterpret_cast<float2*>(dst + 3 * 4 * C::PLANE) = w2sub(patch[1 * 4 + pw], patch[3 * 4 + pw]);
+        }
+    };
+
+    // chunk 0 -> buffer 0, first weight fragments; the loop is entered with no load in flight
+    if (s_on) load_patch(0);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) bring[i] = *reinterpret_cast<const float4*>(wlane + ((i >> 2) * 16 + (i & 3)) * C::SLICE);
+#define SIV_PIN(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
+#pragma unroll
+    for (int i = 0; i < PD; ++i) SIV_PIN(bring[i]);
+#undef SIV_PIN
+    if (s_on) {
+#pragma unroll
+        for (int piece = 0; piece < 8; ++piece) stage_piece(piece, lds);
+    }
+    __syncthreads();
+
+    for (int cc = 0; cc < nchunk; ++cc) {
+        const float* cur = lds + (cc & 1) * C::V_FLOATS;
+        float* nxt = lds + ((cc + 1) & 1) * C::V_FLOATS;
+        const bool more = cc + 1 < nchunk;
+        if (s_on) load_patch((more ? cc + 1 : cc) * C::CK);
+        const float* wc = wlane + (long)cc * C::TAPS * C::SLICE;
+        float4 anext[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) anext[a] = *reinterpret_cast<const float4*>(cur + aoff0 + a * 384);
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {                     // t = kd*4 + pw
+            const int pw = t & 3;
+            float4 av[2];
+            const float4 bv = bring[t % PD];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[a] = anext[a];
+            {   // fragment of tap t + PD (running into the next chunk at the end of this one)
+                const int tn = t + PD;
+                const int sl = tn < 12 ? (tn >> 2) * 16 + (tn & 3) : C::TAPS + ((tn - 12) >> 2) * 16 + ((tn - 12) & 3);
+                bring[t % PD] = *reinterpret_cast<const float4*>(wc + sl * C::SLICE);
+            }
+            if (t + 1 < 12) {
+                const int t1 = t + 1;
+                const int tapoff = (t1 & 3) * C::PLANE + (t1 >> 2) * 192;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) anext[a] = *reinterpret_cast<const float4*>(cur + aoff0 + a * 384 + tapoff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#define SIV_W2STEP(F)                                                                       \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                           \
+        acc[pw][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].F, bv.F, acc[pw][a], 0, 0, 0);
+            SIV_W2STEP(x)
+            SIV_W2STEP(y)
+            SIV_W2STEP(z)
+            SIV_W2STEP(w)
+#undef SIV_W2STEP
+            __builtin_amdgcn_sched_barrier(0);
+            if (t >= 4 && more && s_on) stage_piece(t - 4, nxt);   // the patch loads have had a third of a chunk
+        }
+        __syncthreads();
+    }
+
+    // ---- output transform and store ----
+    // along W on the accumulators: Z[ow] = sum_pw At[ow][pw] M[ph][pw]
+    const int cq = lane & 7;
+    const int co = co0 + wn * 32 + 4 * cq;
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && co < Cout) bq = *reinterpret_cast<const float4*>(bias + co);
+    const int oh = ph & 1, ow = ph >> 1;                   // the output parity this wave combines and stores
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        // tiles E[(ph*2 + wn)*2 + ow'] of 32 rows x 32 channels
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            float* tile = lds + ((ph * 2 + wn) * 2 + o) * C::EPI_TILE;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = o == 0 ? (acc[0][a][r] + acc[1][a][r]) + acc[2][a][r]
+                                       : (acc[1][a][r] - acc[2][a][r]) - acc[3][a][r];
+                tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * C::EPI_STRIDE + li] = v;
+            }
+        }
+        __syncthreads();
+        // along H across the four ph waves: oh = 0: Z0 + Z1 + Z2, oh = 1: Z1 - Z2 - Z3
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = ps * 8 + (lane >> 3);
+            const int off = row * C::EPI_STRIDE + 4 * cq;
+            const float4 za = *reinterpret_cast<const float4*>(lds + (((oh + 0) * 2 + wn) * 2 + ow) * C::EPI_TILE + off);
+            const float4 zb = *reinterpret_cast<const float4*>(lds + (((oh + 1) * 2 + wn) * 2 + ow) * C::EPI_TILE + off);
+            const float4 zc = *reinterpret_cast<const float4*>(lds + (((oh + 2) * 2 + wn) * 2 + ow) * C::EPI_TILE + off);
+            float4 v = oh == 0 ? w2add(w2add(za, zb), zc) : w2sub(w2sub(za, zb), zc);
+            const int m = a * 32 + row;
+            const int gz = z0 + (m >> 4), gy = y0 + 2 * ((m >> 2) & 3) + oh, gx = x0 + 2 * (m & 3) + ow;
+            if (gz < D && gy < H && gx < W && co < Cout) {
+                s1 = w2add(s1, v);
+                s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
+                s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+                v = w2add(v, bq);
+                *reinterpret_cast<float4*>(y + ((((long)n * D + gz) * H + gy) * W + gx) * Cout + co) = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (stat_part) {
+        // lanes with equal cq (bits 3..5 differ) hold the same four channels
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64);
+            s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+            s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64);
+            s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+        }
+        float* red = lds;                  // [8 waves][2 (sum, sumsq)][32 channels]
+        if (lane < 8) {
+            *reinterpret_cast<float4*>(red + (wave * 2 + 0) * 32 + 4 * cq) = s1;
+            *reinterpret_cast<float4*>(red + (wave * 2 + 1) * 32 + 4 * cq) = s2;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int k = tid >> 6, c = tid & 63, w0 = (c >> 5) * 4;
+            float s = 0.f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) s += red[((w0 + p) * 2 + k) * 32 + (c & 31)];
+            if (co0 + c < Cout) stat_part[((long)blockIdx.x * 2 + k) * Cout + co0 + c] = s;
+        }
+    }
+}
+
+// Packed, transformed weights: wp[ct][cc][kd*16 + ph*4 + pw][co (64)][ci (8)] = (G g_kd G^T)[ph][pw].
+//   flip == 0: g[kh][kw] = w[kco][kd][kh][kw][kci]              (w is [Kout][27][Kin])
+//   flip == 1: g[kh][kw] = w[kci][2-kd][2-kh][2-kw][kco]        (w is [Kin][27][Kout]; input gradient)
+__global__ __launch_bounds__(256) void k3_pack_weights_wino2d(const float* __restrict__ w,
+                                                              float* __restrict__ wp, int Kin, int Kout,
+                                                              int flip) {
+    const int nchunk = Kin / 8, ntile = Kout / 64;
+    const long total = (long)ntile * nchunk * 48 * 64 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        long r = i >> 3;
+        const int co = (int)(r & 63); r >>= 6;
+        const int t = (int)(r % 48); r /= 48;
+        const int cc = (int)(r % nchunk);
+        const int ct = (int)(r / nchunk);
+        const int pw = t & 3, ph = (t >> 2) & 3, kd = t >> 4;
+        const int kco = ct * 64 + co, kci = cc * 8 + j;
+        float g[3][3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tap = (kd * 3 + kh) * 3 + kw;
+                g[kh][kw] = flip ? w[((long)kci * 27 + (26 - tap)) * Kout + kco] : w[((long)kco * 27 + tap) * Kin + kci];
+            }
+        // rows of G applied along kw, then along kh
+        float u[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+            u[kh] = pw == 0 ? g[kh][0] : pw == 1 ? 0.5f * ((g[kh][0] + g[kh][1]) + g[kh][2])
+                  : pw == 2 ? 0.5f * ((g[kh][0] - g[kh][1]) + g[kh][2]) : g[kh][2];
+        wp[i] = ph == 0 ? u[0] : ph == 1 ? 0.5f * ((u[0] + u[1]) + u[2]) : ph == 2 ? 0.5f * ((u[0] - u[1]) + u[2]) : u[2];
+    }
+}
+
+bool k3_fwd_wino2d_supported(int Cin, int Cout) { return Cin % 8 == 0 && Cout % 64 == 0; }
+size_t k3_fwd_wino2d_ws_bytes(int Cin, int Cout) {     // one chunk of padding behind the last slice
+    return ((size_t)(Cout / 64) * (Cin / 8) + 1) * 48 * 512 * sizeof(float);
+}
+
+// Same contract as k3_fwd_wino_launch with ups == 1 (stat_part rows: k3_fwd_wino_bricks()).
+int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H,
+                         int W, int Cin, int Cout, int flip, void* ws, size_t ws_bytes, hipStream_t s,
+                         float* stat_part) {
+    SIV_CHECK_WS(k3_fwd_wino2d_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(winograd 2-D)");
+    SIV_CHECK_ARG((long)D * H * W < (1L << 31) / Cin, "conv3d_k3(winograd 2-D): sample too large for 32-bit voxel offsets");
+    const long total = (long)(Cout / 64) * (Cin / 8) * 48 * 512;
+    long g = cdiv(total, 256);
+    if (g > 4096) g = 4096;
+    k3_pack_weights_wino2d<<<(unsigned)g, 256, 0, s>>>(w, (float*)ws, Cin, Cout, flip);
+    SIV_CHECK_LAUNCH("conv3d_k3(pack 2-D winograd weights)");
+    const int nbd = (D + 3) / 4, nbh = (H + 7) / 8, nbw = (W + 7) / 8;
+    const long nblk = (long)N * nbd * nbh * nbw;
+    if (nblk > 0x7fffffffL) {
+        set_error("conv3d_k3(winograd 2-D): too many bricks");
+        return SIV_EINVAL;
+    }
+    if (hipFuncSetAttribute((const void*)k3_fwd_wino2d, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)W2Cfg::LDS_BYTES) != hipSuccess) {
+        set_error("conv3d_k3(winograd 2-D): cannot reserve %zu bytes of LDS", W2Cfg::LDS_BYTES);
+        return SIV_EHIP;
+    }
+    k3_fwd_wino2d<<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 512, W2Cfg::LDS_BYTES, s>>>(
+        x, (const float*)ws, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part);
+    SIV_CHECK_LAUNCH("conv3d_k3(winograd 2-D)");
+    return SIV_OK;
+}
+
+}  // namespace siv

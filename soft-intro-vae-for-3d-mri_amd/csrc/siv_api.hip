@@ -24,7 +24,7 @@ int conv_path() {
     if (env_path < 0) {
         const char* e = getenv("SIV_CONV_PATH");
         const int v = e ? atoi(e) : 0;
-        env_path = (v >= 0 && v <= 5) ? v : 0;
+        env_path = (v >= 0 && v <= 6) ? v : 0;
     }
     return env_path;
 }
@@ -50,6 +50,11 @@ int k3_fwd_wino_launch(const float*, const float*, const float*, float*, int, in
                        int, int, void*, size_t, hipStream_t, float* stat_part);
 long k3_fwd_wino_bricks(int N, int D, int H, int W);
 size_t k3_fwd_wino_ws_bytes(int Cin, int Cout);
+// conv_wino2d.hip
+bool k3_fwd_wino2d_supported(int Cin, int Cout);
+size_t k3_fwd_wino2d_ws_bytes(int Cin, int Cout);
+int k3_fwd_wino2d_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int, int,
+                         void*, size_t, hipStream_t, float*);
 // conv_wino_b3.hip
 bool k3_fwd_wino_b3_supported(int Cin, int Cout);
 size_t k3_fwd_wino_b3_ws_bytes(int Cin, int Cout);
@@ -94,8 +99,13 @@ static int check_conv_shape(const char* what, int N, int D, int H, int W, int Ci
 static bool use_wino(int path, bool aligned, int N, int D, int H, int W, int Cin, int Cout) {
     if (!aligned || !k3_fwd_wino_supported(Cin, Cout)) return false;
     if (path == 3) return true;
-    if (path != 0 && path != 5) return false;
+    if (path != 0 && path < 5) return false;
     return g_auto_wino && (long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8) * (Cout / 64) >= 512;
+}
+
+// Path 6: the two-dimensional Winograd F(2x2,3x3) kernel for the non-upsampled forward / input gradient
+static bool use_w2d(int path, bool aligned, int ups, int Cin, int Cout) {
+    return path == 6 && ups == 1 && aligned && k3_fwd_wino2d_supported(Cin, Cout);
 }
 
 // Path 5: the Winograd kernel whose fp32 products are formed from bf16 triples on the bf16 matrix cores
@@ -106,7 +116,7 @@ static bool use_b3(int path, bool aligned, int ups, int Cin, int Cout) {
 
 // the collapsed-tap kernel for convolutions of an upsampled input (auto and "specialised" paths)
 static bool use_up(int path, bool aligned, int ups, int Cin, int Cout) {
-    return ups == 2 && (path == 0 || path == 2 || path == 5) && aligned && k2_up_fwd_supported(Cin, Cout);
+    return ups == 2 && (path == 0 || path == 2 || path >= 5) && aligned && k2_up_fwd_supported(Cin, Cout);
 }
 
 }  // namespace siv
@@ -117,7 +127,7 @@ extern "C" const char* siv_last_error(void) { return g_err; }
 extern "C" int siv_version(void) { return 100; }
 extern "C" size_t siv_workspace_bytes(void) { return (size_t)512 << 20; }
 extern "C" int siv_set_conv_path(int path) {
-    SIV_CHECK_ARG(path >= 0 && path <= 5, "set_conv_path: path must be 0..5");
+    SIV_CHECK_ARG(path >= 0 && path <= 6, "set_conv_path: path must be 0..6");
     g_conv_path = path;
     return SIV_OK;
 }
@@ -137,6 +147,8 @@ extern "C" int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bi
         return k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, nullptr, path == 5);
     if (use_b3(path, al, ups, Cin, Cout))
         return k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, nullptr);
+    if (use_w2d(path, al, ups, Cin, Cout))
+        return k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, nullptr);
     if (use_wino(path, al, N, D, H, W, Cin, Cout))
         return k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s, nullptr);
     if (path != 1 && al && k3_fwd_mfma_supported(Cin, Cout))
@@ -180,6 +192,16 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
         return bn_finalize_launch(bias, part, (int)nblk, M, Cout, mean, var, running_mean, running_var,
                                   num_batches_tracked, momentum, s);
     }
+    if (use_w2d(conv_path(), al, ups, Cin, Cout)) {
+        const size_t wbytes = align256(k3_fwd_wino2d_ws_bytes(Cin, Cout));
+        const long nblk = k3_fwd_wino_bricks(N, D, H, W);
+        SIV_CHECK_WS(wbytes + (size_t)nblk * 2 * Cout * sizeof(float), ws_bytes, "conv3d_k3_fwd_bnstats");
+        float* part = (float*)((char*)ws + wbytes);
+        rc = k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part);
+        if (rc) return rc;
+        return bn_finalize_launch(bias, part, (int)nblk, M, Cout, mean, var, running_mean, running_var,
+                                  num_batches_tracked, momentum, s);
+    }
     if (use_wino(conv_path(), al, N, D, H, W, Cin, Cout)) {
         // the convolution's epilogue emits per-brick sums of its bias-free output
         const size_t wbytes = align256(k3_fwd_wino_ws_bytes(Cin, Cout));
@@ -211,6 +233,8 @@ extern "C" int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx, i
         return k3_thin_fwd_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, s);
     if (use_b3(path, al, 1, Cout, Cin))
         return k3_fwd_wino_b3_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, ws, ws_bytes, s, nullptr);
+    if (use_w2d(path, al, 1, Cout, Cin))
+        return k3_fwd_wino2d_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, ws, ws_bytes, s, nullptr);
     if (use_wino(path, al, N, D, H, W, Cout, Cin))
         return k3_fwd_wino_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s, nullptr);
     if (path != 1 && al && k3_fwd_mfma_supported(Cout, Cin))
@@ -221,7 +245,7 @@ extern "C" int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx, i
 
 extern "C" int siv_conv3d_k3_dgrad_up_supported(int Cin, int Cout) {
     const int path = conv_path();
-    return (path == 0 || path == 2 || path == 5) && k2_up_dgrad_supported(Cin, Cout) ? 1 : 0;
+    return (path == 0 || path == 2 || path >= 5) && k2_up_dgrad_supported(Cin, Cout) ? 1 : 0;
 }
 
 extern "C" int siv_conv3d_k3_dgrad_up(const float* dy, const float* w, float* dx, int N, int D, int H,
@@ -250,7 +274,7 @@ extern "C" int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, f
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
         return k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
     if (path != 1 && al && k3_wgrad_mfma_supported(Cin, Cout)) {
-        if (ups == 2 && (path == 0 || path == 2 || path == 5) && k2_up_wgrad_supported(Cin, Cout))
+        if (ups == 2 && (path == 0 || path == 2 || path >= 5) && k2_up_wgrad_supported(Cin, Cout))
             rc = k2_up_wgrad_launch(x, dy, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
         else
             rc = k3_wgrad_mfma_launch(x, dy, dw, N, D, H, W, Cin, Cout, ups, accumulate, ws, ws_bytes, s);

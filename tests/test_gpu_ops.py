@@ -91,6 +91,9 @@ CONV_CASES = [
     (16, 64, (10, 24, 20), 1, 1, 5), (72, 64, (4, 6, 10), 1, 1, 5), (64, 64, (16, 16, 16), 1, 1, 5),
     (128, 64, (8, 8, 16), 1, 2, 5), (8, 64, (6, 10, 14), 2, 2, 5), (64, 128, (4, 24, 40), 1, 2, 5),
     (64, 64, (2, 2, 2), 1, 2, 5), (64, 16, (10, 24, 20), 1, 2, 5),
+    # path 6: two-dimensional Winograd F(2x2,3x3)
+    (8, 64, (8, 12, 8), 1, 1, 6), (64, 64, (5, 7, 9), 2, 1, 6), (64, 128, (8, 8, 16), 2, 1, 6),
+    (16, 64, (10, 24, 20), 1, 1, 6), (72, 64, (4, 6, 10), 1, 1, 6), (64, 64, (16, 16, 16), 1, 1, 6),
     # the same wide shapes through the generic kernels (cross-check of the dispatcher)
     (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
 ]
@@ -401,6 +404,7 @@ def test_add_act(B, shape):
     (8, 64, (6, 10, 14), 2, 2, 0, True),               # ... and from the collapsed-tap (upsampled) kernel
     (64, 64, (8, 12, 8), 2, 1, 5, False), (8, 64, (5, 7, 9), 3, 1, 5, True),   # ... and the split-bf16 kernels
     (64, 128, (8, 8, 16), 1, 2, 5, True), (16, 64, (10, 24, 20), 1, 2, 5, False),
+    (64, 64, (8, 12, 8), 2, 1, 6, False), (8, 64, (5, 7, 9), 3, 1, 6, True), (16, 128, (10, 24, 20), 1, 1, 6, True),
     (4, 8, (6, 7, 5), 2, 1, 0, True), (1, 8, (8, 12, 8), 2, 1, 0, True), (64, 64, (10, 12, 10), 1, 1, 0, False),
 ])
 def test_conv_fwd_with_bn_statistics(B, cin, cout, dims, n, ups, path, use_bias):
