@@ -21,6 +21,12 @@
 // waves ph = 0..3 and goes through LDS together with the transposition for 16-byte stores.
 #include "siv_common.h"
 
+// SIV_W2EXP: timing-only ablation mask (never set in the library build): 1 = no staging of the next
+// chunk (16 = no patch loads only, 32 = no transform / LDS writes only), 2 = no barrier per chunk, 4 = no weight-fragment loads, 8 = no LDS fragment reads
+#ifndef SIV_W2EXP
+#define SIV_W2EXP 0
+#endif
+
 namespace siv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     };
 
     // chunk 0 -> buffer 0, first weight fragments; the loop is entered with no load in flight
-    if (s_on) load_patch(0);
+    if (!(SIV_W2EXP & 128)) load_patch(0);
 #pragma unroll
     for (int i = 0; i < PD; ++i) bring[i] = *reinterpret_cast<const float4*>(wlane + ((i >> 2) * 16 + (i & 3)) * C::SLICE);
 #define SIV_PIN(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
@@ -157,7 +163,10 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
         const float* cur = lds + (cc & 1) * C::V_FLOATS;
         float* nxt = lds + ((cc + 1) & 1) * C::V_FLOATS;
         const bool more = cc + 1 < nchunk;
-        if (s_on) load_patch((more ? cc + 1 : cc) * C::CK);
+        // every wave issues the patch loads (waves 6 and 7 re-read voxel 0 and drop it): with one
+        // instruction stream the compiler counts the loads that may stay in flight at each wait
+        // instead of assuming, at the first tap, the path that issued none
+        if (!(SIV_W2EXP & 17)) load_patch((more ? cc + 1 : cc) * C::CK);
         const float* wc = wlane + (long)cc * C::TAPS * C::SLICE;
         float4 anext[2];
 #pragma unroll
@@ -172,13 +181,16 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             {   // fragment of tap t + PD (running into the next chunk at the end of this one)
                 const int tn = t + PD;
                 const int sl = tn < 12 ? (tn >> 2) * 16 + (tn & 3) : C::TAPS + ((tn - 12) >> 2) * 16 + ((tn - 12) & 3);
-                bring[t % PD] = *reinterpret_cast<const float4*>(wc + sl * C::SLICE);
+                if (!(SIV_W2EXP & 4)) bring[t % PD] = *reinterpret_cast<const float4*>(wc + sl * C::SLICE);
             }
             if (t + 1 < 12) {
                 const int t1 = t + 1;
                 const int tapoff = (t1 & 3) * C::PLANE + (t1 >> 2) * 192;
 #pragma unroll
-                for (int a = 0; a < 2; ++a) anext[a] = *reinterpret_cast<const float4*>(cur + aoff0 + a * 384 + tapoff);
+                for (int a = 0; a < 2; ++a) {
+                    if (SIV_W2EXP & 8) asm volatile("" : "+v"(anext[a].x), "+v"(anext[a].y), "+v"(anext[a].z), "+v"(anext[a].w));
+                    else anext[a] = *reinterpret_cast<const float4*>(cur + aoff0 + a * 384 + tapoff);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #define SIV_W2STEP(F)                                                                       \
@@ -190,12 +202,13 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             SIV_W2STEP(w)
 #undef SIV_W2STEP
             __builtin_amdgcn_sched_barrier(0);
-            if (t >= 4 && more && s_on) stage_piece(t - 4, nxt);   // the patch loads have had a third of a chunk
+            if (t >= 4 && more && s_on && !(SIV_W2EXP & 33)) stage_piece(t - 4, nxt);   // the patch loads have had a third of a chunk
         }
-        __syncthreads();
+        if (!(SIV_W2EXP & 2)) __syncthreads();
     }
 
     // ---- output transform and store ----
+    if ((SIV_W2EXP & 64) && acc[0][0][0] != 123.f) return;
     // along W on the accumulators: Z[ow] = sum_pw At[ow][pw] M[ph][pw]
     const int cq = lane & 7;
     const int co = co0 + wn * 32 + 4 * cq;

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}")
 DST = os.path.join(ROOT, "profiles")
-DOM = "k3_fwd_wino<1>"
+DOM = "k3_fwd_wino2d"
 DOM_GRID = "4915200"          # 8 volumes x 80x96x80 / 256-voxel bricks x 256 threads
 ALGO_BYTES = 2 * 8 * 80 * 96 * 80 * 64 * 4 + 27 * 64 * 64 * 4     # read x + write y + weights
 ALGO_FLOP = 2.0 * 27 * 64 * 64 * 80 * 96 * 80 * 8
