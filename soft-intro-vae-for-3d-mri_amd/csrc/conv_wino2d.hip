@@ -40,7 +40,10 @@ struct W2Cfg {
     static constexpr int V_FLOATS = 16 * PLANE;            // 18432 floats = 72 KB
     static constexpr int NTHR = 512, NT = 64;
     static constexpr int TAPS = 48, SLICE = NT * 8;        // (kd, ph, pw) slices of [64 co][8 ci]
-    static constexpr int PD = 4;                           // weight fragments fetched 4 taps ahead
+#ifndef SIV_W2PD
+#define SIV_W2PD 6
+#endif
+    static constexpr int PD = SIV_W2PD;                    // weight fragments fetched PD taps ahead (divides 12)
     static constexpr int EPI_STRIDE = 40, EPI_TILE = 32 * EPI_STRIDE;
     static constexpr int LDS_FLOATS = 2 * V_FLOATS;
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
@@ -107,17 +110,24 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             const bool ok = s_on && pgz >= 0 && pgz < D && pgy + rr >= 0 && pgy + rr < H && pgx + c >= 0 && pgx + c < W;
             pmask |= (unsigned)ok << (rr * 4 + c);
         }
-    const float* xs = x + (long)n * D * H * W * Cin + 2 * s_q;       // this sample, this channel pair
+    // Patch addresses = uniform base (sample, chunk) + a 32-bit per-lane byte offset that is rebuilt from
+    // one register for every chunk: sixteen hoisted 64-bit pointers would cost 32 registers.
+    const char* xs = reinterpret_cast<const char*>(x + (long)n * D * H * W * Cin);
     const int pvox = (pgz * H + pgy) * W + pgx;                       // may lie outside; masked per voxel
+    const int pbyte0 = (pvox * Cin + 2 * s_q) * 4;
+    const int rowb = W * Cin * 4, colb = Cin * 4;
     float2 patch[16];
     auto load_patch = [&](int c0) {
+        int pb = pbyte0;
+        asm volatile("" : "+v"(pb));                                   // keep the offsets out of loop-invariant registers
+        const char* xb = xs + (long)c0 * 4;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int k = rr * 4 + c;
-                const int vox = ((pmask >> k) & 1) ? pvox + rr * W + c : 0;      // out of volume: reads voxel 0
-                patch[k] = *reinterpret_cast<const float2*>(xs + (long)vox * Cin + c0);
+                const unsigned off = ((pmask >> k) & 1) ? (unsigned)(pb + rr * rowb + c * colb) : (unsigned)(8 * s_q);
+                patch[k] = *reinterpret_cast<const float2*>(xb + off);  // out of volume: reads voxel 0
             }
     };
     // The transform is cut into eight pieces that the multiply loop issues between the MFMA groups of
@@ -149,6 +159,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     if (!(SIV_W2EXP & 128)) load_patch(0);
 #pragma unroll
     for (int i = 0; i < PD; ++i) bring[i] = *reinterpret_cast<const float4*>(wlane + ((i >> 2) * 16 + (i & 3)) * C::SLICE);
+    static_assert(12 % PD == 0, "ring index must not depend on the chunk");
 #define SIV_PIN(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
 #pragma unroll
     for (int i = 0; i < PD; ++i) SIV_PIN(bring[i]);
@@ -202,7 +213,12 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             SIV_W2STEP(w)
 #undef SIV_W2STEP
             __builtin_amdgcn_sched_barrier(0);
-            if (t >= 4 && more && s_on && !(SIV_W2EXP & 33)) stage_piece(t - 4, nxt);   // the patch loads have had a third of a chunk
+            // the patch loads get half a chunk before their first use (rows 0..3 at taps 6 and 7)
+            if (more && s_on && !(SIV_W2EXP & 33)) {
+                if (t == 6) { stage_piece(0, nxt); stage_piece(1, nxt); }
+                if (t == 7) { stage_piece(2, nxt); stage_piece(3, nxt); }
+                if (t >= 8) stage_piece(t - 4, nxt);
+            }
         }
         if (!(SIV_W2EXP & 2)) __syncthreads();
     }
@@ -322,7 +338,7 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
                          int W, int Cin, int Cout, int flip, void* ws, size_t ws_bytes, hipStream_t s,
                          float* stat_part) {
     SIV_CHECK_WS(k3_fwd_wino2d_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(winograd 2-D)");
-    SIV_CHECK_ARG((long)D * H * W < (1L << 31) / Cin, "conv3d_k3(winograd 2-D): sample too large for 32-bit voxel offsets");
+    SIV_CHECK_ARG((long)D * H * W * Cin < (1L << 29), "conv3d_k3(winograd 2-D): sample too large for 32-bit byte offsets");
     const long total = (long)(Cout / 64) * (Cin / 8) * 48 * 512;
     long g = cdiv(total, 256);
     if (g > 4096) g = 4096;

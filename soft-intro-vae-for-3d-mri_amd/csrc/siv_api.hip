@@ -111,7 +111,7 @@ static bool big_volume(int N, int D, int H, int W, int Cout) {
 }
 static bool use_w2d(int path, bool aligned, int ups, int N, int D, int H, int W, int Cin, int Cout) {
     if (ups != 1 || !aligned || !k3_fwd_wino2d_supported(Cin, Cout)) return false;
-    if ((long)D * H * W * Cin >= (1L << 31)) return false;      // 32-bit voxel offsets inside a sample
+    if ((long)D * H * W * Cin >= (1L << 29)) return false;      // 32-bit byte offsets inside a sample
     return path == 6 || (path == 0 && g_auto_wino && big_volume(N, D, H, W, Cout));
 }
 
