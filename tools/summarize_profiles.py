@@ -15,7 +15,7 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}")
 DST = os.path.join(ROOT, "profiles")
 DOM = "k3_fwd_wino2d"
-DOM_GRID = "4915200"          # 8 volumes x 80x96x80 / 256-voxel bricks x 256 threads
+DOM_GRID = "9830400"          # 8 volumes x 80x96x80 / 256-voxel bricks x 512 threads
 ALGO_BYTES = 2 * 8 * 80 * 96 * 80 * 64 * 4 + 27 * 64 * 64 * 4     # read x + write y + weights
 ALGO_FLOP = 2.0 * 27 * 64 * 64 * 80 * 96 * 80 * 8
 
@@ -75,12 +75,12 @@ Produced by `tools/profile_round.sh` on one MI355X, summarised by `tools/summari
 | MFMA pipe busy | **{100 * sq["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles:.1f} %** of SIMD-cycles |
 | SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY / SQ_WAIT_ANY / SQ_ACTIVE_INST_ANY | {sq["SQ_WAVE_CYCLES"]:.4g} / {sq["SQ_WAIT_INST_ANY"]:.4g} / {sq["SQ_WAIT_ANY"]:.4g} / {sq["SQ_ACTIVE_INST_ANY"]:.4g} |
 
-Reading: the kernel applies Winograd F(2,3) along W, so it issues 18/27 of the direct-convolution
+Reading: the kernel applies Winograd F(2x2,3x3) over (H, W), so it issues 12/27 of the direct-convolution
 multiply-adds: the TFLOP/s above are ALGORITHMIC (direct-convolution) rates; the matrix pipe itself
-runs at 2/3 of them (MFMA busy ~ that / peak).  The fetch side re-reads the 6x10x10-voxel halo of
-every 4x8x8 brick (2.34x the input, each halo row read as four overlapping columns per output pair)
--- those re-reads are served by L2 / the Infinity Cache (the counter sits on the L2's fabric side and
-includes Infinity-Cache hits) and, at
+runs at 4/9 of them (MFMA busy ~ that / peak).  The fetch side reads, per 4x8x8 brick, the 4x4 input
+patch of every 2x2 output tile of its 6 planes (overlapping patches; 6x10x10 distinct voxels = 2.34x the
+brick) -- the re-reads are served by L1 / L2 / the Infinity Cache (the counter sits on the L2's fabric
+side and includes Infinity-Cache hits) and, at
 {traffic / 1e9 / (avg_ms / 1e3) / 1e3:.2f} TB/s, are far from the HBM roof, so they do not bound the kernel.
 """)
     print("wrote profiles for", TAG, "avg_ms", avg_ms, "traffic GB", traffic / 1e9)
