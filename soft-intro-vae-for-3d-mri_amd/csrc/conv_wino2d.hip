@@ -44,10 +44,10 @@ struct W2Cfg {
 #define SIV_W2PD 6
 #endif
     static constexpr int PD = SIV_W2PD;                    // weight fragments fetched PD taps ahead (divides 12)
-    static constexpr int EPI_STRIDE = 40, EPI_TILE = 32 * EPI_STRIDE;
+    static constexpr int EPI_STRIDE = 36, EPI_TILE = 32 * EPI_STRIDE;
     static constexpr int LDS_FLOATS = 2 * V_FLOATS;
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
-    static_assert(16 * EPI_TILE <= LDS_FLOATS, "epilogue tiles fit");
+    static_assert(32 * EPI_TILE <= LDS_FLOATS, "all 32 epilogue tiles fit at once");
 };
 
 __device__ __forceinline__ float4 w2sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -232,12 +232,12 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     if (bias && co < Cout) bq = *reinterpret_cast<const float4*>(bias + co);
     const int oh = ph & 1, ow = ph >> 1;                   // the output parity this wave combines and stores
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // tiles E[((ph*2 + wn)*2 + ow')*2 + a] of 32 rows x 32 channels: all 32 at once, one barrier
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        // tiles E[(ph*2 + wn)*2 + ow'] of 32 rows x 32 channels
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-            float* tile = lds + ((ph * 2 + wn) * 2 + o) * C::EPI_TILE;
+            float* tile = lds + (((ph * 2 + wn) * 2 + o) * 2 + a) * C::EPI_TILE;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = o == 0 ? (acc[0][a][r] + acc[1][a][r]) + acc[2][a][r]
@@ -245,15 +245,18 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
                 tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * C::EPI_STRIDE + li] = v;
             }
         }
-        __syncthreads();
-        // along H across the four ph waves: oh = 0: Z0 + Z1 + Z2, oh = 1: Z1 - Z2 - Z3
+    }
+    __syncthreads();
+    // along H across the four ph waves: oh = 0: Z0 + Z1 + Z2, oh = 1: Z1 - Z2 - Z3
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int row = ps * 8 + (lane >> 3);
             const int off = row * C::EPI_STRIDE + 4 * cq;
-            const float4 za = *reinterpret_cast<const float4*>(lds + (((oh + 0) * 2 + wn) * 2 + ow) * C::EPI_TILE + off);
-            const float4 zb = *reinterpret_cast<const float4*>(lds + (((oh + 1) * 2 + wn) * 2 + ow) * C::EPI_TILE + off);
-            const float4 zc = *reinterpret_cast<const float4*>(lds + (((oh + 2) * 2 + wn) * 2 + ow) * C::EPI_TILE + off);
+            const float4 za = *reinterpret_cast<const float4*>(lds + ((((oh + 0) * 2 + wn) * 2 + ow) * 2 + a) * C::EPI_TILE + off);
+            const float4 zb = *reinterpret_cast<const float4*>(lds + ((((oh + 1) * 2 + wn) * 2 + ow) * 2 + a) * C::EPI_TILE + off);
+            const float4 zc = *reinterpret_cast<const float4*>(lds + ((((oh + 2) * 2 + wn) * 2 + ow) * 2 + a) * C::EPI_TILE + off);
             float4 v = oh == 0 ? w2add(w2add(za, zb), zc) : w2sub(w2sub(za, zb), zc);
             const int m = a * 32 + row;
             const int gz = z0 + (m >> 4), gy = y0 + 2 * ((m >> 2) & 3) + oh, gx = x0 + 2 * (m & 3) + ow;
@@ -265,7 +268,6 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
                 *reinterpret_cast<float4*>(y + ((((long)n * D + gz) * H + gy) * W + gx) * Cout + co) = v;
             }
         }
-        __syncthreads();
     }
     if (stat_part) {
         // lanes with equal cq (bits 3..5 differ) hold the same four channels
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64);
             s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
         }
+        __syncthreads();                   // the tiles have been read
         float* red = lds;                  // [8 waves][2 (sum, sumsq)][32 channels]
         if (lane < 8) {
             *reinterpret_cast<float4*>(red + (wave * 2 + 0) * 32 + 4 * cq) = s1;
