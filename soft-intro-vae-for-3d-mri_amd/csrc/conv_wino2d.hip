@@ -22,7 +22,8 @@
 #include "siv_common.h"
 
 // SIV_W2EXP: timing-only ablation mask (never set in the library build): 1 = no staging of the next
-// chunk (16 = no patch loads only, 32 = no transform / LDS writes only), 2 = no barrier per chunk, 4 = no weight-fragment loads, 8 = no LDS fragment reads
+// chunk (16 = no patch loads only, 32 = no transform / LDS writes only), 2 = no barrier per chunk,
+// 4 = no weight-fragment loads, 8 = no LDS fragment reads, 64 = no epilogue, 128 = no first patch loads
 #ifndef SIV_W2EXP
 #define SIV_W2EXP 0
 #endif
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             }
     };
     // The transform is cut into eight pieces that the multiply loop issues between the MFMA groups of
-    // eight consecutive taps, so that the matrix pipe never waits for a block of vector instructions:
+    // its last six taps, so that the matrix pipe never waits for a long block of vector instructions:
     // pieces 0..3 transform patch row 0..3 along W in place, pieces 4..7 finish column pw = 0..3 along H
     // and write its four positions.
     auto stage_piece = [&](int piece, float* buf) {
