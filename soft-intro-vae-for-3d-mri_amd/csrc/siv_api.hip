@@ -1,14 +1,14 @@
 // C-ABI entry points that dispatch between the convolution kernel families, plus the
 // library-wide helpers (error string, version, workspace size, test overrides).
 #include "siv_common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 
 namespace siv {
 
 static thread_local char g_err[512] = "";
-static int g_conv_path = 0;
-static const bool g_auto_wino = true;
+static std::atomic<int> g_conv_path{0};
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -19,13 +19,13 @@ void set_error(const char* fmt, ...) {
 // Path 0 ("automatic") resolves to the value of the environment variable SIV_CONV_PATH when that is
 // set (e.g. SIV_CONV_PATH=5 runs a whole training job on the split-bf16 kernels), else to 0.
 int conv_path() {
-    if (g_conv_path != 0) return g_conv_path;
-    static int env_path = -1;
-    if (env_path < 0) {
+    const int forced = g_conv_path.load(std::memory_order_relaxed);
+    if (forced != 0) return forced;
+    static const int env_path = [] {
         const char* e = getenv("SIV_CONV_PATH");
         const int v = e ? atoi(e) : 0;
-        env_path = (v >= 0 && v <= 6) ? v : 0;
-    }
+        return (v >= 0 && v <= 6) ? v : 0;
+    }();
     return env_path;
 }
 
@@ -55,6 +55,10 @@ bool k3_fwd_wino2d_supported(int Cin, int Cout);
 size_t k3_fwd_wino2d_ws_bytes(int Cin, int Cout);
 int k3_fwd_wino2d_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int, int,
                          void*, size_t, hipStream_t, float*);
+// conv_wgrad_wino.hip
+bool k3_wgrad_wino2d_supported(int Cin, int Cout);
+int k3_wgrad_wino2d_launch(const float*, const float*, float*, int, int, int, int, int, int, int, void*, size_t,
+                           hipStream_t);
 // conv_wino_b3.hip
 bool k3_fwd_wino_b3_supported(int Cin, int Cout);
 size_t k3_fwd_wino_b3_ws_bytes(int Cin, int Cout);
@@ -94,25 +98,40 @@ static int check_conv_shape(const char* what, int N, int D, int H, int W, int Ci
     return SIV_OK;
 }
 
-// Winograd F(2,3) path: on request (path 3), or automatically (path 0) for volumes large enough to
-// fill the chip with 4x8x8 bricks.  Path 4 = matrix-core kernels without Winograd.
+// A volume is "big" when its 4x8x8 bricks times its 64-channel output tiles fill the chip twice over;
+// the Winograd kernels (one block per brick and tile) only pay off from there.
+static bool big_volume(int N, int D, int H, int W, int Cout) {
+    return (long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8) * (Cout / 64) >= 512;
+}
+
+// Winograd F(2,3) path: on request (path 3), or as the fallback of the automatic paths for big volumes
+// that the two-dimensional kernel cannot take.  Path 4 = matrix-core kernels without Winograd.
 static bool use_wino(int path, bool aligned, int N, int D, int H, int W, int Cin, int Cout) {
     if (!aligned || !k3_fwd_wino_supported(Cin, Cout)) return false;
     if (path == 3) return true;
     if (path != 0 && path < 5) return false;
-    return g_auto_wino && (long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8) * (Cout / 64) >= 512;
+    return big_volume(N, D, H, W, Cout);
 }
 
 // Two-dimensional Winograd F(2x2,3x3) kernel for the non-upsampled forward / input gradient: on request
-// (path 6) and automatically (path 0) for the volumes the one-dimensional kernel used to take (measured
-// 13-18 % faster there; slower on the 10x12x10 level, which stays on the direct kernel).
-static bool big_volume(int N, int D, int H, int W, int Cout) {
-    return (long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 7) / 8) * (Cout / 64) >= 512;
-}
+// (path 6) and automatically (path 0) for big volumes (measured 13-18 % faster than the one-dimensional
+// kernel there; slower on the 10x12x10 level, which stays on the direct kernel).
 static bool use_w2d(int path, bool aligned, int ups, int N, int D, int H, int W, int Cin, int Cout) {
     if (ups != 1 || !aligned || !k3_fwd_wino2d_supported(Cin, Cout)) return false;
     if ((long)D * H * W * Cin >= (1L << 29)) return false;      // 32-bit byte offsets inside a sample
-    return path == 6 || (path == 0 && g_auto_wino && big_volume(N, D, H, W, Cout));
+    return path == 6 || (path == 0 && big_volume(N, D, H, W, Cout));
+}
+
+// Winograd F(3x3,2x2) weight gradient: on request (path 6) and automatically where it was measured
+// faster than the direct kernel (1.7-1.95x from 20x24x20 upwards at batch 8; equal at 10x12x10): enough
+// column steps to keep its 256 blocks busy, planes that fill at least 60 % of their 8x8 columns
+static bool use_gw(int path, bool aligned, int ups, int N, int D, int H, int W, int Cin, int Cout) {
+    if (ups != 1 || !aligned || !k3_wgrad_wino2d_supported(Cin, Cout)) return false;
+    if ((long)H * W * (Cin > Cout ? Cin : Cout) >= (1L << 29)) return false;
+    if (path == 6) return true;
+    if (path != 0 && path != 5) return false;
+    const long nrh = (H + 7) / 8, nrw = (W + 7) / 8;
+    return (long)N * nrh * nrw * D >= 1024 && 10L * H * W >= 6L * nrh * nrw * 64;
 }
 
 // Path 5: the Winograd kernel whose fp32 products are formed from bf16 triples on the bf16 matrix cores
@@ -135,7 +154,7 @@ extern "C" int siv_version(void) { return 100; }
 extern "C" size_t siv_workspace_bytes(void) { return (size_t)512 << 20; }
 extern "C" int siv_set_conv_path(int path) {
     SIV_CHECK_ARG(path >= 0 && path <= 6, "set_conv_path: path must be 0..6");
-    g_conv_path = path;
+    g_conv_path.store(path, std::memory_order_relaxed);
     return SIV_OK;
 }
 
@@ -179,43 +198,31 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
     hipStream_t s = (hipStream_t)stream;
     const long M = (long)N * D * H * W;
     const bool al = aligned16(x) && aligned16(w) && aligned16(y) && aligned16(ws);
-    if (use_up(conv_path(), al, ups, Cin, Cout)) {
-        const size_t wbytes = align256(k2_up_fwd_ws_bytes(Cin, Cout));
-        const long nblk = k2_up_fwd_blocks(N, D, H, W);
-        SIV_CHECK_WS(wbytes + (size_t)nblk * 2 * Cout * sizeof(float), ws_bytes, "conv3d_k3_fwd_bnstats");
-        float* part = (float*)((char*)ws + wbytes);
-        rc = k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, part, conv_path() == 5);
-        if (rc) return rc;
-        return bn_finalize_launch(bias, part, (int)nblk, M, Cout, mean, var, running_mean, running_var,
-                                  num_batches_tracked, momentum, s);
+    // Kernels whose epilogue emits per-block sums of their bias-free output: the statistics then cost
+    // one small finalize launch instead of a pass over y.  The partials sit behind the packed weights.
+    const int path = conv_path();
+    enum { NONE, UP, B3, W2D, WINO } fused = NONE;
+    size_t wbytes = 0;
+    long nblk = 0;
+    if (use_up(path, al, ups, Cin, Cout)) {
+        fused = UP, wbytes = k2_up_fwd_ws_bytes(Cin, Cout), nblk = k2_up_fwd_blocks(N, D, H, W);
+    } else if (use_b3(path, al, ups, Cin, Cout)) {
+        fused = B3, wbytes = k3_fwd_wino_b3_ws_bytes(Cin, Cout), nblk = k3_fwd_wino_bricks(N, D, H, W);
+    } else if (use_w2d(path, al, ups, N, D, H, W, Cin, Cout)) {
+        fused = W2D, wbytes = k3_fwd_wino2d_ws_bytes(Cin, Cout), nblk = k3_fwd_wino_bricks(N, D, H, W);
+    } else if (use_wino(path, al, N, D, H, W, Cin, Cout)) {
+        fused = WINO, wbytes = k3_fwd_wino_ws_bytes(Cin, Cout), nblk = k3_fwd_wino_bricks(N, D, H, W);
     }
-    if (use_b3(conv_path(), al, ups, Cin, Cout)) {
-        const size_t wbytes = align256(k3_fwd_wino_b3_ws_bytes(Cin, Cout));
-        const long nblk = k3_fwd_wino_bricks(N, D, H, W);
+    if (fused != NONE) {
+        wbytes = align256(wbytes);
         SIV_CHECK_WS(wbytes + (size_t)nblk * 2 * Cout * sizeof(float), ws_bytes, "conv3d_k3_fwd_bnstats");
         float* part = (float*)((char*)ws + wbytes);
-        rc = k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part);
-        if (rc) return rc;
-        return bn_finalize_launch(bias, part, (int)nblk, M, Cout, mean, var, running_mean, running_var,
-                                  num_batches_tracked, momentum, s);
-    }
-    if (use_w2d(conv_path(), al, ups, N, D, H, W, Cin, Cout)) {
-        const size_t wbytes = align256(k3_fwd_wino2d_ws_bytes(Cin, Cout));
-        const long nblk = k3_fwd_wino_bricks(N, D, H, W);
-        SIV_CHECK_WS(wbytes + (size_t)nblk * 2 * Cout * sizeof(float), ws_bytes, "conv3d_k3_fwd_bnstats");
-        float* part = (float*)((char*)ws + wbytes);
-        rc = k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part);
-        if (rc) return rc;
-        return bn_finalize_launch(bias, part, (int)nblk, M, Cout, mean, var, running_mean, running_var,
-                                  num_batches_tracked, momentum, s);
-    }
-    if (use_wino(conv_path(), al, N, D, H, W, Cin, Cout)) {
-        // the convolution's epilogue emits per-brick sums of its bias-free output
-        const size_t wbytes = align256(k3_fwd_wino_ws_bytes(Cin, Cout));
-        const long nblk = k3_fwd_wino_bricks(N, D, H, W);
-        SIV_CHECK_WS(wbytes + (size_t)nblk * 2 * Cout * sizeof(float), ws_bytes, "conv3d_k3_fwd_bnstats");
-        float* part = (float*)((char*)ws + wbytes);
-        rc = k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s, part);
+        switch (fused) {
+        case UP: rc = k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, part, path == 5); break;
+        case B3: rc = k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part); break;
+        case W2D: rc = k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part); break;
+        default: rc = k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s, part); break;
+        }
         if (rc) return rc;
         return bn_finalize_launch(bias, part, (int)nblk, M, Cout, mean, var, running_mean, running_var,
                                   num_batches_tracked, momentum, s);
@@ -280,6 +287,12 @@ extern "C" int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, f
     const bool al = aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(ws);
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
         return k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
+    if (use_gw(path, al, ups, N, D, H, W, Cin, Cout)) {
+        rc = k3_wgrad_wino2d_launch(x, dy, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
+        if (rc) return rc;
+        if (dbias) return colsum_launch(dy, dbias, (long)N * D * H * W, Cout, accumulate, ws, ws_bytes, s);
+        return SIV_OK;
+    }
     if (path != 1 && al && k3_wgrad_mfma_supported(Cin, Cout)) {
         if (ups == 2 && (path == 0 || path == 2 || path >= 5) && k2_up_wgrad_supported(Cin, Cout))
             rc = k2_up_wgrad_launch(x, dy, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);

@@ -94,6 +94,10 @@ CONV_CASES = [
     # path 6: two-dimensional Winograd F(2x2,3x3)
     (8, 64, (8, 12, 8), 1, 1, 6), (64, 64, (5, 7, 9), 2, 1, 6), (64, 128, (8, 8, 16), 2, 1, 6),
     (16, 64, (10, 24, 20), 1, 1, 6), (72, 64, (4, 6, 10), 1, 1, 6), (64, 64, (16, 16, 16), 1, 1, 6),
+    # ... and the Winograd F(3x3,2x2) weight gradient (multiples of 64 channels): ragged planes, several
+    # channel tiles, columns cut along z (D = 40 with one column)
+    (128, 64, (9, 10, 12), 1, 1, 6), (128, 128, (6, 12, 20), 2, 1, 6), (64, 64, (17, 8, 24), 3, 1, 6),
+    (256, 256, (2, 4, 8), 1, 1, 6), (64, 64, (40, 8, 8), 1, 1, 6), (64, 192, (3, 9, 9), 2, 1, 6),
     # the same wide shapes through the generic kernels (cross-check of the dispatcher)
     (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
 ]
@@ -129,6 +133,29 @@ def test_conv3d_k3_fwd_dgrad_wgrad(B, cin, cout, dims, n, ups, path):
     check(dw2, gw, "wgrad (no bias)")
     check(db, gb, "bias grad")
     assert y.is_contiguous(memory_format=torch.channels_last_3d)
+
+
+@pytest.mark.parametrize("path", [0, 6])
+def test_conv_wgrad_accumulates(B, path):
+    """accumulate = 1 adds to dw / dbias instead of overwriting them (C-ABI call)."""
+    import siv._lib as L
+    from siv.backend import cl, empty_cl, _p
+    gen = torch.Generator().manual_seed(11)
+    x = cl(dev(rnd(gen, 2, 64, 6, 8, 8)))
+    dy = cl(dev(rnd(gen, 2, 64, 6, 8, 8)))
+    base = cl(dev(rnd(gen, 64, 64, 3, 3, 3)))
+    bias0 = dev(rnd(gen, 64))
+    B.set_conv_path(path)
+    try:
+        dw_ref, db_ref = B.conv3d_k3_wgrad(x, dy, 1, True)
+        dw, db = base.clone(memory_format=torch.preserve_format), bias0.clone()
+        ws, wsb = B._workspace(dy)
+        L.check(B.lib.siv_conv3d_k3_wgrad(_p(x), _p(dy), _p(dw), _p(db), 2, 6, 8, 8, 64, 64, 1, 1, ws, wsb,
+                                          B._stream(dy)), "siv_conv3d_k3_wgrad")
+    finally:
+        B.set_conv_path(0)
+    check(dw, base + dw_ref, "wgrad accumulate")
+    check(db, bias0 + db_ref, "bias grad accumulate")
 
 
 def test_conv_rejects_bad_arguments(B):
