@@ -15,15 +15,22 @@
 //              transformed patch V[z] meets the transformed dy planes U[z+1], U[z], U[z-1] (kd = 0, 1, 2)
 //   LDS      = ring of four U planes + two V planes, [position][channel][tile], 20 KB each
 //
-// Both operands come from LDS, so the global loads of the staging have no other loads behind them:
-// they are issued right after their registers were consumed and land a whole step later.  Waves 0..3
-// stage x (two patch rows suffice for one ph), waves 4..7 stage dy; the transform is cut into pieces
-// that sit between the MFMA groups.
+// Both operands come from LDS, so the global loads of the staging have no other loads behind them and
+// every wait on them is exact.  Waves 0..3 stage x (two patch rows suffice for one ph), waves 4..7 stage
+// dy; each role runs its own copy of the multiply loop, a single basic block in which the transform is
+// cut into units that follow single pairs of matrix instructions.
 #include "siv_common.h"
+
+// SIV_GWEXP: timing-only ablation mask (never set in the library build): 1 = no global loads of the
+// staging, 2 = no transform / LDS writes, 4 = no barrier per step, 8 = no LDS fragment reads
+#ifndef SIV_GWEXP
+#define SIV_GWEXP 0
+#endif
 
 namespace siv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GwCfg {
     static constexpr int RH = 8, RW = 8;                 // output voxels of a column per plane
@@ -37,9 +44,154 @@ struct GwCfg {
     static constexpr int NBLOCKS = 256;                  // one per CU; every block owns 1/64 of the columns
 };
 
-__device__ __forceinline__ float4 gw_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 gw_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 gw_half(float4 a) { return make_float4(0.5f * a.x, 0.5f * a.y, 0.5f * a.z, 0.5f * a.w); }
+struct GwGeom {
+    int N, D, H, W, nrh, nrw, zsplit, nsets;
+};
+
+// The work of one wave over all items of its block.  ISV: the wave stages x (4x4 patch, two rows of it
+// for position row ph), else dy (2x2 tile).  `src` points at the lane's four channels of voxel 0, `Cs`
+// is the channel count of that tensor.  The row combination is written with coefficients instead of
+// cases, so that the multiply loop is one basic block per role:
+//   x:  h = a + sB b         (sB = +1 for ph = 1, else -1; rows (A, B) = (0,2) (1,2) (2,1) (3,1))
+//   dy: h = a/2 + sB b       (sB = -1/2 for ph = 2, else 1/2; rows (0,0) (0,1) (0,1) (1,1))
+// with the coefficients of voxels outside the volume set to zero (their loads read voxel 0).
+template <bool ISV>
+__device__ __forceinline__ void gw_run(const float* __restrict__ src, const int Cs, f32x16 (&acc)[3][2],
+                                       float* lds, const int ph, const int set, const GwGeom g,
+                                       const int aoff, const int boff, const int cg, const int tile) {
+    using C = GwCfg;
+    constexpr int NC = ISV ? 4 : 2;
+    const int th = tile >> 2, tw = tile & 3;
+    const int soff = (4 * cg) * C::CS + tile;                          // + position * 64 * CS + e * CS
+    const int rA = ISV ? ph : (ph == 3 ? 1 : 0);
+    const int rB = ISV ? (ph <= 1 ? 2 : 1) : (ph == 0 ? 0 : 1);
+    const float kA = ISV ? 1.f : 0.5f;
+    const float kB = ISV ? (ph == 1 ? 1.f : -1.f) : (ph == 2 ? -0.5f : 0.5f);
+    const long plane = (long)g.H * g.W * Cs;
+
+    f32x4 pa[NC], pb[NC];
+    int oa[NC], ob[NC];
+    float ca[NC], cb[NC];
+    const float* sn = src;
+
+    auto issue_col = [&](int c, int z) {
+        if (SIV_GWEXP & 1) return;
+        z = z < 0 ? 0 : z >= g.D ? g.D - 1 : z;
+        const float* pl = sn + (long)z * plane;
+        pa[c] = *reinterpret_cast<const f32x4*>(pl + oa[c]);
+        pb[c] = *reinterpret_cast<const f32x4*>(pl + ob[c]);
+    };
+    // rows A and B of column c combined in place (zs = 0 for a plane outside the volume)
+    auto hxf_col = [&](int c, float zs) {
+        const float fa = ca[c] * zs, fb = cb[c] * zs;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pa[c][e] = __builtin_fmaf(fb, pb[c][e], fa * pa[c][e]);
+    };
+    // transform along W for position (ph, p), then its four channel rows
+    auto wpiece = [&](int p, float* dst) {
+        f32x4 v;
+        if (ISV) v = p == 0 ? pa[0] - pa[NC - 2] : p == 1 ? pa[1] + pa[NC - 2] : p == 2 ? pa[NC - 2] - pa[1] : pa[NC - 1] - pa[1];
+        else v = p == 0 ? pa[0] : p == 1 ? 0.5f * pa[0] + 0.5f * pa[1] : p == 2 ? 0.5f * pa[0] - 0.5f * pa[1] : pa[1];
+        float* d = dst + p * 64 * C::CS + soff;
+        d[0] = v[0]; d[C::CS] = v[1]; d[2 * C::CS] = v[2]; d[3 * C::CS] = v[3];
+    };
+    auto vbuf = [&](int z) { return lds + (C::NU + (z & 1)) * C::BUF; };
+    auto ubuf = [&](int z) { return lds + (z & 3) * C::BUF; };
+    auto zscale = [&](int z) { return (z >= 0 && z < g.D) ? 1.f : 0.f; };
+    // immediate staging of one plane (pipeline fill)
+    auto stage_now = [&](int z) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) issue_col(c, z);
+        const float zs = zscale(z);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) hxf_col(c, zs);
+        float* dst = ISV ? vbuf(z) : ubuf(z);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) wpiece(p, dst);
+    };
+
+    const int nitems = g.N * g.nrh * g.nrw * g.zsplit;
+    for (int item = set; item < nitems; item += g.nsets) {
+        int r = item / g.zsplit;
+        const int zp = item - r * g.zsplit;
+        const int rx = r % g.nrw; r /= g.nrw;
+        const int ry = r % g.nrh;
+        const int n = r / g.nrh;
+        const int zlo = (int)((long)zp * g.D / g.zsplit), zhi = (int)((long)(zp + 1) * g.D / g.zsplit);
+        if (zlo >= zhi) continue;
+
+        // offsets and coefficients of this item's 2 x NC voxels
+        const int gy0 = ry * C::RH + 2 * th + (ISV ? -1 : 0), gx0 = rx * C::RW + 2 * tw + (ISV ? -1 : 0);
+        const bool okA = gy0 + rA >= 0 && gy0 + rA < g.H, okB = gy0 + rB >= 0 && gy0 + rB < g.H;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bool okx = gx0 + c >= 0 && gx0 + c < g.W;
+            oa[c] = (okx && okA) ? ((gy0 + rA) * g.W + gx0 + c) * Cs : 0;
+            ob[c] = (okx && okB) ? ((gy0 + rB) * g.W + gx0 + c) * Cs : 0;
+            ca[c] = (okx && okA) ? kA : 0.f;
+            cb[c] = (okx && okB) ? kB : 0.f;
+        }
+        sn = src + (long)n * g.D * plane;
+
+        // fill: V[zlo], U[zlo-1], U[zlo], U[zlo+1]; then the loads of the first step's staging
+        if (ISV) {
+            stage_now(zlo);
+        } else {
+            stage_now(zlo - 1);
+            stage_now(zlo);
+            stage_now(zlo + 1);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) issue_col(c, ISV ? zlo + 1 : zlo + 2);
+        __syncthreads();
+
+        for (int z = zlo; z < zhi; ++z) {
+            const float* vb = vbuf(z);
+            const float* u[3] = {ubuf(z + 1), ubuf(z), ubuf(z - 1)};
+            // this step stages x-plane z + 1 / dy-plane z + 2 (loaded during the previous step) and
+            // fetches the planes after them; past the end of the item both are harmless extra work
+            const int zst = ISV ? z + 1 : z + 2;
+            float* dst = ISV ? vbuf(zst) : ubuf(zst);
+            const float zs = zscale(zst);
+            f32x4 af[2][2], bf[2][3];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    if (SIV_GWEXP & 8) af[j][a] = f32x4{(float)z, 1.f, 2.f, 3.f};
+                    else af[j][a] = *reinterpret_cast<const f32x4*>(vb + aoff + a * 32 * C::CS + 8 * j);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (SIV_GWEXP & 8) bf[j][k] = f32x4{(float)z, 1.f, 2.f, 3.f};
+                    else bf[j][k] = *reinterpret_cast<const f32x4*>(u[k] + boff + 8 * j);
+                }
+            }
+            // 24 MFMA pairs; the staging is cut into units that follow single pairs, so that the vector
+            // and LDS instructions of a wave run in the shadow of its own matrix instructions
+#pragma unroll
+            for (int m = 0; m < 24; ++m) {
+                const int gq = m >> 2, e = m & 3;
+                const int j = gq / 3, k = gq % 3;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    acc[k][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][a][e], bf[j][k][e], acc[k][a], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(SIV_GWEXP & 2)) {
+                    if (m >= 2 && m < 2 + NC) hxf_col(m - 2, zs);
+                    if (m == 8 || m == 11 || m == 14 || m == 17) wpiece((m - 8) / 3, dst);
+                }
+                // The loads of the next planes go last, into the registers the transform has just
+                // released.  (Issued earlier, into registers of their own, they cost 5-15 % more: a
+                // wave that issues 1 KB loads between its matrix instructions holds those back, while
+                // at the end of the step the issue overlaps the wait at the barrier.)
+                if (m >= 20 && m - 20 < NC) issue_col(m - 20, zst + 1);
+            }
+            if (!(SIV_GWEXP & 4)) __syncthreads();
+        }
+    }
+}
 
 // part[set][channel tile][ph][pw][kd][ci (64)][co (64)]
 __global__ __launch_bounds__(512, 2) void k3_wgrad_wino2d(const float* __restrict__ x,
@@ -72,136 +224,12 @@ __global__ __launch_bounds__(512, 2) void k3_wgrad_wino2d(const float* __restric
 
     const int aoff = (pw * 64 + li) * C::CS + 4 * lh;                 // + ci half * 32 * CS + 8 j
     const int boff = (pw * 64 + coh * 32 + li) * C::CS + 4 * lh;      // + 8 j
-
     // staging item: (tile, group of four channels); waves 0..3: x, waves 4..7: dy
-    const bool isV = wave < 4;
     const int st = tid & 255;
     const int cg = st & 15, tile = st >> 4;
-    const int th = tile >> 2, tw = tile & 3;
-    const int soff = (4 * cg) * C::CS + tile;                          // + position * 64 * CS + e * CS
-    // rows of the 4x4 patch (x) / of the 2x2 tile (dy) that position row ph combines
-    const int rA = isV ? (ph == 0 ? 0 : ph == 1 ? 1 : ph == 2 ? 2 : 3) : (ph == 3 ? 1 : 0);
-    const int rB = isV ? (ph == 0 ? 2 : ph == 1 ? 2 : 1) : (ph == 0 ? 0 : 1);
-    const int Cs = isV ? Cin : Cout;                                   // channels of the staged tensor
-    const float* sbase = isV ? x + cit * 64 + 4 * cg : dy + cot * 64 + 4 * cg;
-    const int ncol = isV ? 4 : 2;
-    const long plane = (long)H * W * Cs;
-
-    float4 pa[4], pb[4];
-    const int nitems = N * nrh * nrw * zsplit;
-    for (int item = set; item < nitems; item += nsets) {
-        int r = item / zsplit;
-        const int zp = item - r * zsplit;
-        const int rx = r % nrw; r /= nrw;
-        const int ry = r % nrh;
-        const int n = r / nrh;
-        const int zlo = (int)((long)zp * D / zsplit), zhi = (int)((long)(zp + 1) * D / zsplit);
-        if (zlo >= zhi) continue;
-
-        // first row / column of this item's rows A and B, validity of its (up to) 2 x 4 voxels
-        const int gy0 = ry * C::RH + 2 * th + (isV ? -1 : 0), gx0 = rx * C::RW + 2 * tw + (isV ? -1 : 0);
-        unsigned mask = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const bool okx = c < ncol && gx0 + c >= 0 && gx0 + c < W;
-            mask |= (unsigned)(okx && gy0 + rA >= 0 && gy0 + rA < H) << c;
-            mask |= (unsigned)(okx && gy0 + rB >= 0 && gy0 + rB < H) << (4 + c);
-        }
-        const int offA = ((gy0 + rA) * W + gx0) * Cs, offB = ((gy0 + rB) * W + gx0) * Cs;
-        const float* sn = sbase + (long)n * D * plane;
-
-        // loads of x-plane zv (waves 0..3) / dy-plane zu (waves 4..7); out of range: any valid address
-        auto issue = [&](int zv, int zu) {
-            int z = isV ? zv : zu;
-            z = z < 0 ? 0 : z >= D ? D - 1 : z;
-            const float* pl = sn + (long)z * plane;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c < 2 || isV) {
-                    pa[c] = *reinterpret_cast<const float4*>(pl + (((mask >> c) & 1) ? offA + c * Cs : 0));
-                    pb[c] = *reinterpret_cast<const float4*>(pl + (((mask >> (4 + c)) & 1) ? offB + c * Cs : 0));
-                }
-            }
-        };
-        // transform along H into pa[] (zeros for voxels outside the volume)
-        auto hxf = [&](int zv, int zu) {
-            const int z = isV ? zv : zu;
-            const unsigned m = (z >= 0 && z < D) ? mask : 0u;
-            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c < 2 || isV) {
-                    const float4 a = ((m >> c) & 1) ? pa[c] : zero;
-                    const float4 bb = ((m >> (4 + c)) & 1) ? pb[c] : zero;
-                    if (isV) pa[c] = ph == 1 ? gw_add(a, bb) : gw_sub(a, bb);
-                    else pa[c] = (ph == 0 || ph == 3) ? a : ph == 1 ? gw_half(gw_add(a, bb)) : gw_half(gw_sub(a, bb));
-                }
-            }
-        };
-        // transform along W for position (ph, p) and its four channel rows
-        auto wpiece = [&](int p, float* vdst, float* udst) {
-            float4 v;
-            if (isV) v = p == 0 ? gw_sub(pa[0], pa[2]) : p == 1 ? gw_add(pa[1], pa[2]) : p == 2 ? gw_sub(pa[2], pa[1]) : gw_sub(pa[3], pa[1]);
-            else v = p == 0 ? pa[0] : p == 1 ? gw_half(gw_add(pa[0], pa[1])) : p == 2 ? gw_half(gw_sub(pa[0], pa[1])) : pa[1];
-            float* d = (isV ? vdst : udst) + p * 64 * C::CS + soff;
-            d[0] = v.x; d[C::CS] = v.y; d[2 * C::CS] = v.z; d[3 * C::CS] = v.w;
-        };
-        auto vbuf = [&](int z) { return lds + (C::NU + (z & 1)) * C::BUF; };
-        auto ubuf = [&](int z) { return lds + (z & 3) * C::BUF; };
-
-        // fill: V[zlo], U[zlo-1], U[zlo], U[zlo+1]; the loads of the first step's staging in flight
-        issue(zlo, zlo - 1);
-        hxf(zlo, zlo - 1);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) wpiece(p, vbuf(zlo), ubuf(zlo - 1));
-        if (!isV) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                issue(0, zlo + k);
-                hxf(0, zlo + k);
-#pragma unroll
-                for (int p = 0; p < 4; ++p) wpiece(p, nullptr, ubuf(zlo + k));
-            }
-        }
-        if (zlo + 1 < zhi) issue(zlo + 1, zlo + 2);
-        __syncthreads();
-
-        for (int z = zlo; z < zhi; ++z) {
-            const float* vb = vbuf(z);
-            const float* u[3] = {ubuf(z + 1), ubuf(z), ubuf(z - 1)};
-            const bool more = z + 1 < zhi;
-            float* vdst = vbuf(z + 1);
-            float* udst = ubuf(z + 2);
-            float4 af[2][2], bf[2][3];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a) af[j][a] = *reinterpret_cast<const float4*>(vb + aoff + a * 32 * C::CS + 8 * j);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) bf[j][k] = *reinterpret_cast<const float4*>(u[k] + boff + 8 * j);
-            }
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-                const int j = g / 3, k = g % 3;
-                __builtin_amdgcn_sched_barrier(0);
-#define SIV_GWSTEP(F)                                                                       \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                           \
-        acc[k][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][a].F, bf[j][k].F, acc[k][a], 0, 0, 0);
-                SIV_GWSTEP(x)
-                SIV_GWSTEP(y)
-                SIV_GWSTEP(z)
-                SIV_GWSTEP(w)
-#undef SIV_GWSTEP
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) {
-                    if (g == 1) hxf(z + 1, z + 2);
-                    if (g >= 2) wpiece(g - 2, vdst, udst);
-                }
-            }
-            if (z + 2 < zhi) issue(z + 2, z + 3);
-            __syncthreads();
-        }
-    }
+    const GwGeom g = {N, D, H, W, nrh, nrw, zsplit, nsets};
+    if (wave < 4) gw_run<true>(x + cit * 64 + 4 * cg, Cin, acc, lds, ph, set, g, aoff, boff, cg, tile);
+    else gw_run<false>(dy + cot * 64 + 4 * cg, Cout, acc, lds, ph, set, g, aoff, boff, cg, tile);
 
     // partial sums of this block
     float* pp = part + ((((long)set * gridDim.y + blockIdx.y) * 4 + ph) * 4 + pw) * 3 * 4096;
