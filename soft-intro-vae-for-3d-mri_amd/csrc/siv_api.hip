@@ -123,15 +123,15 @@ static bool use_w2d(int path, bool aligned, int ups, int N, int D, int H, int W,
 }
 
 // Winograd F(3x3,2x2) weight gradient: on request (path 6) and automatically where it was measured
-// faster than the direct kernel (1.7-1.95x from 20x24x20 upwards at batch 8; equal at 10x12x10): enough
-// column steps to keep its 256 blocks busy, planes that fill at least 60 % of their 8x8 columns
+// faster than the direct kernel (1.85-2.15x from 20x24x20 upwards at batch 8, 1.1x at 10x12x10): enough
+// column steps to keep its 256 blocks busy, planes that fill at least 45 % of their 8x8 columns
 static bool use_gw(int path, bool aligned, int ups, int N, int D, int H, int W, int Cin, int Cout) {
     if (ups != 1 || !aligned || !k3_wgrad_wino2d_supported(Cin, Cout)) return false;
     if ((long)H * W * (Cin > Cout ? Cin : Cout) >= (1L << 29)) return false;
     if (path == 6) return true;
     if (path != 0 && path != 5) return false;
     const long nrh = (H + 7) / 8, nrw = (W + 7) / 8;
-    return (long)N * nrh * nrw * D >= 1024 && 10L * H * W >= 6L * nrh * nrw * 64;
+    return (long)N * nrh * nrw * D >= 256 && 100L * H * W >= 45L * nrh * nrw * 64;
 }
 
 // Path 5: the Winograd kernel whose fp32 products are formed from bf16 triples on the bf16 matrix cores
