@@ -27,6 +27,9 @@
 #ifndef SIV_W2EXP
 #define SIV_W2EXP 0
 #endif
+#ifndef SIV_W2LATE
+#define SIV_W2LATE 1
+#endif
 
 namespace siv {
 
@@ -169,6 +172,9 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
 #pragma unroll
         for (int piece = 0; piece < 8; ++piece) stage_piece(piece, lds);
     }
+#if SIV_W2LATE
+    if (!(SIV_W2EXP & 17)) load_patch((nchunk > 1 ? 1 : 0) * C::CK);
+#endif
     __syncthreads();
 
     for (int cc = 0; cc < nchunk; ++cc) {
@@ -178,7 +184,9 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
         // every wave issues the patch loads (waves 6 and 7 re-read voxel 0 and drop it): with one
         // instruction stream the compiler counts the loads that may stay in flight at each wait
         // instead of assuming, at the first tap, the path that issued none
+#if !SIV_W2LATE
         if (!(SIV_W2EXP & 17)) load_patch((more ? cc + 1 : cc) * C::CK);
+#endif
         const float* wc = wlane + (long)cc * C::TAPS * C::SLICE;
         float4 anext[2];
 #pragma unroll
@@ -221,6 +229,11 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
                 if (t >= 8) stage_piece(t - 4, nxt);
             }
         }
+#if SIV_W2LATE
+        // the patch of the chunk after next goes out right behind the last pieces of this one: its
+        // issue overlaps the wait at the barrier and it has a chunk and a half to arrive
+        if (!(SIV_W2EXP & 17)) load_patch((cc + 2 < nchunk ? cc + 2 : cc) * C::CK);
+#endif
         if (!(SIV_W2EXP & 2)) __syncthreads();
     }
 
