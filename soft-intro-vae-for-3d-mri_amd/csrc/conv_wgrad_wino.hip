@@ -244,6 +244,15 @@ __global__ __launch_bounds__(512, 2) void k3_wgrad_wino2d(const float* __restric
             }
 }
 
+// part[0][e] = sum_s part[s][e] in fixed order (every thread owns its elements: safe in place)
+__global__ __launch_bounds__(256) void gw_sum_sets(float* __restrict__ part, int nsets, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsets; ++k) s += part[(long)k * n + i];
+        part[i] = s;
+    }
+}
+
 // dw[co][kd][kh][kw][ci] (+)= sum_{ph,pw} At[kh][ph] At[kw][pw] sum_set part[set][tile][ph][pw][kd][ci][co]
 __global__ __launch_bounds__(256) void k3_wgrad_wino2d_finish(const float* __restrict__ part, int nsets,
                                                               int ntile, float* __restrict__ dw, int Cin,
@@ -280,6 +289,301 @@ __global__ __launch_bounds__(256) void k3_wgrad_wino2d_finish(const float* __res
             else { o[0] = g0; o[Cin] = g1; o[2 * Cin] = g2; }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same weight-gradient-stationary kernel for a convolution of a nearest x2 upsampled input
+// (x is the LOW-resolution tensor).  Along H and W the 4x4 patch of an upsampled plane around a 2x2
+// tile is (a, b, b, c) per axis, so B^T x = (a - b, 2 b, 0, c - b): one tile = one low-resolution
+// voxel and its 3x3 neighbourhood, and only the 3 x 3 positions {0, 1, 3}^2 are non-zero.  Along z
+// the planes pair up: with s the low-resolution plane,
+//   P00 = sum dy[2s] x[s-1],  P01 = sum dy[2s] x[s],  P10 = sum dy[2s+1] x[s],  P11 = sum dy[2s+1] x[s+1]
+//   dW[kd=0] = P00 + P10,  dW[1] = P01 + P10,  dW[2] = P01 + P11
+// i.e. per x-plane s the transformed patch V[s] meets U[2s+2], U[2s], U[2s+1], U[2s-1]: 9 positions x 4
+// pairings = 36 multiply-adds per low-resolution voxel and channel pair for 8 outputs (4.5 per output;
+// the collapsed-tap kernel issues 8, the direct one 27).
+//   a block = one position row (ph in {0, 1, 3}) x 64 ci x 64 co: 3 positions x 4 pairings x 4 tiles;
+//             wave (pairing, co half) owns 3 positions x 2 ci halves = 96 accumulator registers
+//   LDS     = ring of six U planes + two V planes of 3 positions, 15 KB each
+// ---------------------------------------------------------------------------------------------
+struct GuCfg {
+    static constexpr int CS = 20;
+    static constexpr int BUF = 3 * 64 * CS;
+    static constexpr int NU = 6, NV = 2;
+    static constexpr int LDS_FLOATS = (NU + NV) * BUF;
+    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);   // 120 KB
+    static constexpr int NTHR = 512;
+    static constexpr int NBLOCKS = 255;                  // 3 position rows x 85 sets
+};
+
+// ISV: the wave stages x (low resolution; NP = 1 plane per step), else dy (NP = 2 planes per step).
+// D, H, W in `g` are the full-resolution extents.
+template <bool ISV>
+__device__ __forceinline__ void gu_run(const float* __restrict__ src, const int Cs, f32x16 (&acc)[3][2],
+                                       float* lds, const int phi, const int set, const GwGeom g,
+                                       const int aoff, const int boff, const int zt, const int cg,
+                                       const int tile) {
+    using C = GuCfg;
+    constexpr int NC = ISV ? 3 : 2, NP = ISV ? 1 : 2;
+    const int th = tile >> 2, tw = tile & 3;
+    const int soff = (4 * cg) * C::CS + tile;
+    const int Dl = g.D >> 1, Hs = ISV ? g.H >> 1 : g.H, Ws = ISV ? g.W >> 1 : g.W, Ds = ISV ? Dl : g.D;
+    // rows combined for position row phi (positions 0, 1, 3):
+    //   x:  (jy-1, jy; 1, -1)  (jy, jy; 1, 1)  (jy+1, jy; 1, -1)      dy: (0, 0) (0, 1) (1, 1), halves
+    const int rA = ISV ? phi - 1 : (phi == 2 ? 1 : 0);
+    const int rB = ISV ? 0 : (phi == 0 ? 0 : 1);
+    const float kA = ISV ? 1.f : 0.5f;
+    const float kB = ISV ? (phi == 1 ? 1.f : -1.f) : 0.5f;
+    const long plane = (long)Hs * Ws * Cs;
+
+    f32x4 pa[NP][NC], pb[NP][NC];
+    int oa[NC], ob[NC];
+    float ca[NC], cb[NC];
+    const float* sn = src;
+
+    auto issue_col = [&](int q, int c, int z) {
+        z = z < 0 ? 0 : z >= Ds ? Ds - 1 : z;
+        const float* pl = sn + (long)z * plane;
+        pa[q][c] = *reinterpret_cast<const f32x4*>(pl + oa[c]);
+        pb[q][c] = *reinterpret_cast<const f32x4*>(pl + ob[c]);
+    };
+    auto hxf_col = [&](int q, int c, float zs) {
+        const float fa = ca[c] * zs, fb = cb[c] * zs;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pa[q][c][e] = __builtin_fmaf(fb, pb[q][c][e], fa * pa[q][c][e]);
+    };
+    // position (phi, p), p = 0, 1, 2 standing for 0, 1, 3
+    auto wpiece = [&](int q, int p, float* dst) {
+        f32x4 v;
+        if (ISV) v = p == 0 ? pa[q][0] - pa[q][1] : p == 1 ? pa[q][1] + pa[q][1] : pa[q][NC - 1] - pa[q][1];
+        else v = p == 0 ? pa[q][0] : p == 1 ? 0.5f * pa[q][0] + 0.5f * pa[q][1] : pa[q][1];
+        float* d = dst + p * 64 * C::CS + soff;
+        d[0] = v[0]; d[C::CS] = v[1]; d[2 * C::CS] = v[2]; d[3 * C::CS] = v[3];
+    };
+    auto vbuf = [&](int z) { return lds + (C::NU + (z & 1)) * C::BUF; };
+    auto ubuf = [&](int z) { return lds + ((z + 6) % 6) * C::BUF; };        // z >= -1
+    auto zscale = [&](int z) { return (z >= 0 && z < Ds) ? 1.f : 0.f; };
+    auto stage_now = [&](int z) {                      // planes z .. z + NP - 1
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) issue_col(q, c, z + q);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const float zs = zscale(z + q);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) hxf_col(q, c, zs);
+            float* dst = ISV ? vbuf(z + q) : ubuf(z + q);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) wpiece(q, p, dst);
+        }
+    };
+
+    const int nitems = g.N * g.nrh * g.nrw * g.zsplit;
+    for (int item = set; item < nitems; item += g.nsets) {
+        int r = item / g.zsplit;
+        const int zp = item - r * g.zsplit;
+        const int rx = r % g.nrw; r /= g.nrw;
+        const int ry = r % g.nrh;
+        const int n = r / g.nrh;
+        const int slo = (int)((long)zp * Dl / g.zsplit), shi = (int)((long)(zp + 1) * Dl / g.zsplit);
+        if (slo >= shi) continue;
+
+        // x: low-resolution voxel (ry*4 + th, rx*4 + tw) and its neighbours; dy: its 2x2 tile
+        const int gy0 = ISV ? ry * 4 + th : 2 * (ry * 4 + th), gx0 = ISV ? rx * 4 + tw - 1 : 2 * (rx * 4 + tw);
+        const bool okA = gy0 + rA >= 0 && gy0 + rA < Hs, okB = gy0 + rB >= 0 && gy0 + rB < Hs;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bool okx = gx0 + c >= 0 && gx0 + c < Ws;
+            oa[c] = (okx && okA) ? ((gy0 + rA) * Ws + gx0 + c) * Cs : 0;
+            ob[c] = (okx && okB) ? ((gy0 + rB) * Ws + gx0 + c) * Cs : 0;
+            ca[c] = (okx && okA) ? kA : 0.f;
+            cb[c] = (okx && okB) ? kB : 0.f;
+        }
+        sn = src + (long)n * Ds * plane;
+
+        // fill: V[slo], U[2 slo - 1 .. 2 slo + 2]; then the loads of the first step's staging
+        if (ISV) {
+            stage_now(slo);
+        } else {
+            stage_now(2 * slo - 1);
+            stage_now(2 * slo + 1);
+        }
+        const int zfirst = ISV ? slo + 1 : 2 * slo + 3;
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) issue_col(q, c, zfirst + q);
+        __syncthreads();
+
+        for (int z = slo; z < shi; ++z) {
+            const float* vb = vbuf(z);
+            const float* ub = ubuf(2 * z + (zt == 0 ? 2 : zt == 1 ? 0 : zt == 2 ? 1 : -1));
+            // this step stages x-plane z + 1 / dy-planes 2 z + 3, 2 z + 4 and fetches the ones after them
+            const int zst = ISV ? z + 1 : 2 * z + 3;
+            float* dst0 = ISV ? vbuf(zst) : ubuf(zst);
+            float* dst1 = ISV ? dst0 : ubuf(zst + 1);
+            const float zs0 = zscale(zst), zs1 = zscale(zst + 1);
+            f32x4 af[2][3][2], bf[2][3];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+                        af[j][p][a] = *reinterpret_cast<const f32x4*>(vb + aoff + (p * 64 + a * 32) * C::CS + 8 * j);
+                    bf[j][p] = *reinterpret_cast<const f32x4*>(ub + boff + p * 64 * C::CS + 8 * j);
+                }
+#pragma unroll
+            for (int m = 0; m < 24; ++m) {
+                const int gq = m >> 2, e = m & 3;
+                const int j = gq / 3, p = gq % 3;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    acc[p][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][p][a][e], bf[j][p][e], acc[p][a], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ISV) {
+                    if (m >= 2 && m < 5) hxf_col(0, m - 2, zs0);
+                    if (m == 8 || m == 11 || m == 14) wpiece(0, (m - 8) / 3, dst0);
+                    if (m >= 20 && m < 23) issue_col(0, m - 20, zst + 1);
+                } else {
+                    if (m >= 2 && m < 6) hxf_col((m - 2) >> 1, (m - 2) & 1, (m - 2) >> 1 ? zs1 : zs0);
+                    if (m >= 7 && m < 19 && ((m - 7) & 1) == 0) wpiece((m - 7) / 6, ((m - 7) >> 1) % 3, (m - 7) / 6 ? dst1 : dst0);
+                    if (m >= 20) issue_col((m - 20) >> 1, (m - 20) & 1, zst + 2 + ((m - 20) >> 1));
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// part[set][channel tile][phi (3)][p (3)][pairing (4)][ci (64)][co (64)]
+__global__ __launch_bounds__(512, 2) void k2_up_wgrad_wino(const float* __restrict__ x,
+                                                           const float* __restrict__ dy,
+                                                           float* __restrict__ part, int N, int D, int H, int W,
+                                                           int Cin, int Cout, int nrh, int nrw, int zsplit,
+                                                           int nsets) {
+    using C = GuCfg;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int zt = wave & 3, coh = wave >> 2;
+    const int phi = blockIdx.x % 3, set = blockIdx.x / 3;
+    const int ncot = Cout >> 6;
+    const int cit = blockIdx.y / ncot, cot = blockIdx.y % ncot;
+
+    f32x16 acc[3][2];          // [p][ci half]
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[k][a][r] = 0.f;
+
+    const int aoff = li * C::CS + 4 * lh;
+    const int boff = (coh * 32 + li) * C::CS + 4 * lh;
+    const int st = tid & 255;
+    const int cg = st & 15, tile = st >> 4;
+    const GwGeom g = {N, D, H, W, nrh, nrw, zsplit, nsets};
+    if (wave < 4) gu_run<true>(x + cit * 64 + 4 * cg, Cin, acc, lds, phi, set, g, aoff, boff, zt, cg, tile);
+    else gu_run<false>(dy + cot * 64 + 4 * cg, Cout, acc, lds, phi, set, g, aoff, boff, zt, cg, tile);
+
+    float* pp = part + (((long)set * gridDim.y + blockIdx.y) * 3 + phi) * 12 * 4096;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                pp[((p * 4 + zt) * 64 + ci) * 64 + coh * 32 + li] = acc[p][a][r];
+            }
+}
+
+__global__ __launch_bounds__(256) void k2_up_wgrad_wino_finish(const float* __restrict__ part, int nsets,
+                                                               int ntile, float* __restrict__ dw, int Cin,
+                                                               int Cout, int accumulate) {
+    const long total = (long)ntile * 4096;
+    const int ncot = Cout >> 6;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i & 63), ci = (int)((i >> 6) & 63), tl = (int)(i >> 12);
+        float m[36];                       // [phi][p][pairing]
+#pragma unroll
+        for (int q = 0; q < 36; ++q) m[q] = 0.f;
+        {   // the sets have been summed into part[0] (gw_sum_sets)
+            const float* pp = part + (long)tl * 36 * 4096 + ci * 64 + co;
+#pragma unroll
+            for (int q = 0; q < 36; ++q) m[q] = pp[(long)q * 4096];
+        }
+        const int cog = (tl % ncot) * 64 + co, cig = (tl / ncot) * 64 + ci;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            // pairings of plane offset kd: 0 <- P00 + P10, 1 <- P01 + P10, 2 <- P01 + P11
+            const int z0 = kd == 0 ? 0 : 1, z1 = kd == 2 ? 3 : 2;
+            float t[3][3];                 // [phi][p]
+#pragma unroll
+            for (int q = 0; q < 9; ++q) t[q / 3][q % 3] = m[q * 4 + z0] + m[q * 4 + z1];
+            // positions (0, 1, 3) -> taps: 0 <- T0 + T1, 1 <- T1, 2 <- T3 + T1, along H then W
+            float u[3][3];                 // [kh][p]
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                u[0][q] = t[0][q] + t[1][q];
+                u[1][q] = t[1][q];
+                u[2][q] = t[2][q] + t[1][q];
+            }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const float g0 = u[kh][0] + u[kh][1], g1 = u[kh][1], g2 = u[kh][2] + u[kh][1];
+                float* o = dw + ((long)cog * 27 + (kd * 3 + kh) * 3) * Cin + cig;
+                if (accumulate) { o[0] += g0; o[Cin] += g1; o[2 * Cin] += g2; }
+                else { o[0] = g0; o[Cin] = g1; o[2 * Cin] = g2; }
+            }
+        }
+    }
+}
+
+static int gu_nsets(int Cin, int Cout) {
+    int n = GuCfg::NBLOCKS / (3 * (Cin / 64) * (Cout / 64));
+    return n < 1 ? 1 : n;
+}
+size_t k2_up_wgrad_wino_ws_bytes(int Cin, int Cout) {
+    return (size_t)gu_nsets(Cin, Cout) * (Cin / 64) * (Cout / 64) * 36 * 4096 * sizeof(float);
+}
+
+// x: [N][D/2][H/2][W/2][Cin], dy: [N][D][H][W][Cout] (D, H, W even), Cin % 64 == 0, Cout % 64 == 0
+int k2_up_wgrad_wino_launch(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Cin,
+                            int Cout, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+    SIV_CHECK_WS(k2_up_wgrad_wino_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3_wgrad(upsampled, winograd)");
+    SIV_CHECK_ARG((long)H * W * (Cin > Cout ? Cin : Cout) < (1L << 29),
+                  "conv3d_k3_wgrad(upsampled, winograd): plane too large for 32-bit offsets");
+    const int ntile = (Cin / 64) * (Cout / 64);
+    const int nsets = gu_nsets(Cin, Cout);
+    const int nrh = (H + 7) / 8, nrw = (W + 7) / 8;
+    const long ncol = (long)N * nrh * nrw;
+    int zsplit = 1;
+    while (ncol * zsplit < 12L * nsets && (D / 2) / (zsplit * 2) >= 5) zsplit *= 2;
+    if (ncol * zsplit > 0x7fffffffL) {
+        set_error("conv3d_k3_wgrad(upsampled, winograd): too many columns");
+        return SIV_EINVAL;
+    }
+    if (hipFuncSetAttribute((const void*)k2_up_wgrad_wino, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)GuCfg::LDS_BYTES) != hipSuccess) {
+        set_error("conv3d_k3_wgrad(upsampled, winograd): cannot reserve %zu bytes of LDS", GuCfg::LDS_BYTES);
+        return SIV_EHIP;
+    }
+    k2_up_wgrad_wino<<<dim3((unsigned)(nsets * 3), (unsigned)ntile), GuCfg::NTHR, GuCfg::LDS_BYTES, s>>>(
+        x, dy, (float*)ws, N, D, H, W, Cin, Cout, nrh, nrw, zsplit, nsets);
+    SIV_CHECK_LAUNCH("conv3d_k3_wgrad(upsampled, winograd)");
+    const long nel = (long)ntile * 36 * 4096;
+    gw_sum_sets<<<(unsigned)cdiv(nel, 256), 256, 0, s>>>((float*)ws, nsets, nel);
+    SIV_CHECK_LAUNCH("conv3d_k3_wgrad(upsampled, winograd, sum)");
+    const long total = (long)ntile * 4096;
+    k2_up_wgrad_wino_finish<<<(unsigned)cdiv(total, 256), 256, 0, s>>>((const float*)ws, nsets, ntile, dw, Cin,
+                                                                         Cout, accumulate);
+    SIV_CHECK_LAUNCH("conv3d_k3_wgrad(upsampled, winograd, finish)");
+    return SIV_OK;
 }
 
 bool k3_wgrad_wino2d_supported(int Cin, int Cout) {

@@ -59,6 +59,8 @@ int k3_fwd_wino2d_launch(const float*, const float*, const float*, float*, int, 
 bool k3_wgrad_wino2d_supported(int Cin, int Cout);
 int k3_wgrad_wino2d_launch(const float*, const float*, float*, int, int, int, int, int, int, int, void*, size_t,
                            hipStream_t);
+int k2_up_wgrad_wino_launch(const float*, const float*, float*, int, int, int, int, int, int, int, void*, size_t,
+                            hipStream_t);
 // conv_wino_b3.hip
 bool k3_fwd_wino_b3_supported(int Cin, int Cout);
 size_t k3_fwd_wino_b3_ws_bytes(int Cin, int Cout);
@@ -126,12 +128,12 @@ static bool use_w2d(int path, bool aligned, int ups, int N, int D, int H, int W,
 // faster than the direct kernel (1.85-2.15x from 20x24x20 upwards at batch 8, 1.1x at 10x12x10): enough
 // column steps to keep its 256 blocks busy, planes that fill at least 45 % of their 8x8 columns
 static bool use_gw(int path, bool aligned, int ups, int N, int D, int H, int W, int Cin, int Cout) {
-    if (ups != 1 || !aligned || !k3_wgrad_wino2d_supported(Cin, Cout)) return false;
+    if (!aligned || !k3_wgrad_wino2d_supported(Cin, Cout)) return false;
     if ((long)H * W * (Cin > Cout ? Cin : Cout) >= (1L << 29)) return false;
     if (path == 6) return true;
     if (path != 0 && path != 5) return false;
     const long nrh = (H + 7) / 8, nrw = (W + 7) / 8;
-    return (long)N * nrh * nrw * D >= 256 && 100L * H * W >= 45L * nrh * nrw * 64;
+    return (long)N * nrh * nrw * (D / ups) >= 256 && 100L * H * W >= 45L * nrh * nrw * 64;
 }
 
 // Path 5: the Winograd kernel whose fp32 products are formed from bf16 triples on the bf16 matrix cores
@@ -288,7 +290,8 @@ extern "C" int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, f
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
         return k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
     if (use_gw(path, al, ups, N, D, H, W, Cin, Cout)) {
-        rc = k3_wgrad_wino2d_launch(x, dy, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
+        rc = ups == 2 ? k2_up_wgrad_wino_launch(x, dy, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s)
+                      : k3_wgrad_wino2d_launch(x, dy, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
         if (rc) return rc;
         if (dbias) return colsum_launch(dy, dbias, (long)N * D * H * W, Cout, accumulate, ws, ws_bytes, s);
         return SIV_OK;

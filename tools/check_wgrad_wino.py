@@ -45,6 +45,27 @@ for (n, cin, cout, dims) in ((2, 64, 64, (8, 8, 8)), (1, 64, 64, (5, 6, 7)), (2,
 if not ok:
     sys.exit(1)
 
+# upsampled input (x at low resolution)
+for (n, cin, cout, dims) in ((2, 64, 64, (8, 8, 8)), (1, 64, 64, (6, 10, 14)), (2, 64, 128, (4, 16, 8)),
+                             (1, 128, 64, (10, 12, 20)), (3, 64, 64, (18, 8, 24)), (1, 64, 64, (40, 8, 8))):
+    D, H, W = dims
+    x = torch.randn(n, cin, D // 2, H // 2, W // 2, generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    dy = torch.randn(n, cout, *dims, generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
+    xu = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
+    ref = ref_wgrad(xu, dy)
+    res = {}
+    for path in (4, 0, 6):
+        B.set_conv_path(path)
+        res[path] = B.conv3d_k3_wgrad(x, dy, 2, False)[0].double().cpu()
+    B.set_conv_path(0)
+    scale = ref.abs().max().item()
+    e = {k: (v - ref).abs().max().item() / scale for k, v in res.items()}
+    flag = "ok" if e[6] < 1e-5 else "FAIL"
+    ok = ok and e[6] < 1e-5
+    print(f"up n={n} {cin:3d}->{cout:3d} {dims}: direct {e[4]:.2e} collapsed {e[0]:.2e} winograd {e[6]:.2e}  {flag}", flush=True)
+if not ok:
+    sys.exit(1)
+
 # accumulate flag
 x = torch.randn(2, 64, 8, 8, 8, generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
 dy = torch.randn(2, 64, 8, 8, 8, generator=g).to(dev).contiguous(memory_format=torch.channels_last_3d)
@@ -61,6 +82,29 @@ wx = torch.randn(4096, 4096, device=dev)
 for _ in range(20):
     wx @ wx
 torch.cuda.synchronize()
+UPS = (("v0_64_64_up", 64, 64, (80, 96, 80)), ("v1_128_64_up", 128, 64, (40, 48, 40)),
+       ("v2_256_128_up", 256, 128, (20, 24, 20)))
+for name, cin, cout, (D, H, W) in UPS:
+    x = torch.randn(8, cin, D // 2, H // 2, W // 2, device=dev).contiguous(memory_format=torch.channels_last_3d)
+    dy = torch.randn(8, cout, D, H, W, device=dev).contiguous(memory_format=torch.channels_last_3d)
+    flop = 2.0 * 27 * cin * cout * D * H * W * 8
+    line = f"{name:14s}"
+    outs = {}
+    for path in (2, 6):
+        B.set_conv_path(path)
+        outs[path] = B.conv3d_k3_wgrad(x, dy, 2, False)[0]
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            B.conv3d_k3_wgrad(x, dy, 2, False)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        line += f"  path {path}: {ms:7.3f} ms {flop / ms / 1e9:6.1f} TF/s"
+    B.set_conv_path(0)
+    d = ((outs[2] - outs[6]).abs().max() / outs[2].abs().max()).item()
+    print(line + f"  max diff {d:.2e}", flush=True)
 for name, cin, cout, (D, H, W) in SHAPES:
     x = torch.randn(8, cin, D, H, W, device=dev).contiguous(memory_format=torch.channels_last_3d)
     dy = torch.randn(8, cout, D, H, W, device=dev).contiguous(memory_format=torch.channels_last_3d)
