@@ -782,7 +782,13 @@ struct UdCfg {
 // dy: [N][D][H][W][Cout] (D, H, W even); dx: [N][D/2][H/2][W/2][Cin]; wp: see k2_up_pack_dgrad.
 // SPLIT: every fp32 product formed from three bf16 pieces per operand on the bf16 matrix cores (scheme
 // and operand packing: conv_wino_b3.hip); the staged dy voxels then hold [h | m | l] pieces of 8 channels.
-template <int LBD, int LBH, int LBW, bool SPLIT>
+// BOX (fp32 only): along H and W the four collapsed taps are regrouped around the ORIGINAL taps,
+//   sum_u q[u] dy[2j+u] = w0 (dy[2j+1] + dy[2j+2]) + w1 (dy[2j] + dy[2j+1]) + w2 (dy[2j-1] + dy[2j]),
+// so a tap (kh, kw) multiplies the 2x2 in-plane box sum of dy that starts at (2j+1-kh, 2j+1-kw): 9 taps
+// per staged plane instead of 16 (36 instead of 64 per low-resolution voxel).  The box sums are formed
+// from four LDS reads while the operand is fetched; staging, layout and epilogue are unchanged.  Only
+// the order of the fp32 additions differs from the 16-tap form.
+template <int LBD, int LBH, int LBW, bool SPLIT, bool BOX = false>
 __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ dy,
                                                       const void* __restrict__ wpv,
                                                       float* __restrict__ dx, int N, int D, int H, int W,
@@ -825,9 +831,11 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
         aoff2[a] = row + (lh ? 0 : 4);
         aoff3[a] = row + (lh ? 4 : 8);
     }
-    constexpr int PD = 4;
+    constexpr int PD = BOX ? 3 : 4;             // divides the taps of a step: the ring index restarts with it
+    static_assert((BOX ? 9 : C::TAPS) % PD == 0, "ring index must not depend on the step");
     // fp32: one [64 ci][8 co] slice per tap; SPLIT: two operand slices of [64 ci][2 lane halves][8 co] bf16
-    const float* wlane = (const float*)wpv + (long)blockIdx.y * nstep * C::TAPS * C::SLICE + (wn * 32 + li) * 8 + 4 * lh;
+    constexpr int NTAP = BOX ? 9 : C::TAPS;
+    const float* wlane = (const float*)wpv + (long)blockIdx.y * nstep * NTAP * C::SLICE + (wn * 32 + li) * 8 + 4 * lh;
     const uint4* wlq = (const uint4*)wpv + (long)blockIdx.y * nstep * C::TAPS * 256 + (wn * 32 + li) * 2 + lh;
     float4 bring[PD];
     uint4 bxr[PD], byr[PD];
@@ -937,7 +945,59 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
             }
             continue;
         }
-        const float* wc = wlane + (long)step * C::TAPS * C::SLICE;
+        const float* wc = wlane + (long)step * NTAP * C::SLICE;
+        if constexpr (BOX) {
+            // raw voxels (row e_h + i, column e_w + j), i, j in {0, 1}, of the W-parity-split image
+            auto boxoff = [&](int t, int i, int j) {
+                const int eh = t / 3 + i, px = t % 3 + j;
+                return eh * C::PITCH + ((px & 1) * C::HWH + (px >> 1)) * C::CKP;
+            };
+            // The operand of tap t + 1 is gathered while tap t multiplies: row tile a's four reads go
+            // out before matrix group a and are summed behind it (16 registers in flight, not 64).
+            float4 anext[C::AM], raw[4];
+            auto fetch = [&](int t, int a) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    raw[q] = *reinterpret_cast<const float4*>(lds + aoff[a] + boxoff(t, q >> 1, q & 1));
+            };
+            auto boxsum = [&](int a) {
+                anext[a].x = (raw[0].x + raw[1].x) + (raw[2].x + raw[3].x);
+                anext[a].y = (raw[0].y + raw[1].y) + (raw[2].y + raw[3].y);
+                anext[a].z = (raw[0].z + raw[1].z) + (raw[2].z + raw[3].z);
+                anext[a].w = (raw[0].w + raw[1].w) + (raw[2].w + raw[3].w);
+            };
+#pragma unroll
+            for (int a = 0; a < C::AM; ++a) {
+                fetch(0, a);
+                boxsum(a);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float4 av[C::AM];
+                const float4 bv = bring[t % PD];
+#pragma unroll
+                for (int a = 0; a < C::AM; ++a) av[a] = anext[a];
+                bring[t % PD] = *reinterpret_cast<const float4*>(wc + (t + PD) * C::SLICE);
+                const bool nx = t + 1 < 9;
+                if (nx) fetch(t + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#define SIV_BSTEP(F, A)                                                                     \
+    _Pragma("unroll") for (int a = 0; a < C::AM; ++a)                                       \
+        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].F, bv.F, acc[a], 0, 0, 0);      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    if (nx) {                                                                               \
+        boxsum(A);                                                                          \
+        if (A + 1 < C::AM) fetch(t + 1, A + 1);                                             \
+    }                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);
+                SIV_BSTEP(x, 0)
+                SIV_BSTEP(y, 1)
+                SIV_BSTEP(z, 2)
+                SIV_BSTEP(w, 3)
+#undef SIV_BSTEP
+            }
+            continue;
+        }
         float4 anext[C::AM];
 #pragma unroll
         for (int a = 0; a < C::AM; ++a) anext[a] = *reinterpret_cast<const float4*>(lds + aoff[a]);
@@ -1021,6 +1081,32 @@ __global__ __launch_bounds__(256) void k2_up_pack_dgrad(const float* __restrict_
     }
 }
 
+// The box form: wp[ct][cc][ud][t = e_h * 3 + e_w][ci (64)][co (8)] = sum over the taps kd that collapse
+// onto ud of w[co][kd][2 - e_h][2 - e_w][ci] (the box that starts e rows below 2j - 1 belongs to tap 2 - e).
+__global__ __launch_bounds__(256) void k2_up_pack_dgrad_box(const float* __restrict__ w, float* __restrict__ wp,
+                                                            int Kin, int Kout) {
+    const int nchunk = Kout / 8, ntile = (Kin + 63) / 64;
+    const long total = (long)ntile * nchunk * 4 * 9 * 64 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        long r = i >> 3;
+        const int ci = (int)(r & 63); r >>= 6;
+        const int t = (int)(r % 9); r /= 9;
+        const int ud = (int)(r & 3); r >>= 2;
+        const int cc = (int)(r % nchunk);
+        const int ct = (int)(r / nchunk);
+        const int kh = 2 - t / 3, kw = 2 - t % 3;
+        const int kci = ct * 64 + ci, kco = cc * 8 + j;
+        float v = 0.f;
+        if (kci < Kin) {
+            const int d0 = ud == 0 ? 2 : ud == 1 ? 1 : 0, d1 = ud <= 1 ? 2 : ud == 2 ? 1 : 0;
+            for (int kd = d0; kd <= d1; ++kd) v += w[((long)kco * 27 + (kd * 3 + kh) * 3 + kw) * Kin + kci];
+        }
+        wp[i] = v;
+    }
+}
+
 // The same kernel as bf16 pieces: per (ci tile, co chunk, ud, tap) two operand slices of
 // [64 ci][2 lane halves][8 co]: slice 0 = (h | m), slice 1 = (h | l).
 __global__ __launch_bounds__(256) void k2_up_pack_dgrad_b3(const float* __restrict__ w, __bf16* __restrict__ wp,
@@ -1058,7 +1144,7 @@ size_t k2_up_dgrad_ws_bytes(int Cin, int Cout) {   // sized for the split-bf16 p
     return ((size_t)(Cin / 64) * (Cout / 8) * 64 + 4) * 4096;
 }
 
-template <int LBD, int LBH, int LBW, bool SPLIT>
+template <int LBD, int LBH, int LBW, bool SPLIT, bool BOX = false>
 static int up_dgrad_cfg(const float* dy, const void* wp, float* dx, int N, int D, int H, int W, int Cin,
                         int Cout, hipStream_t s) {
     using C = UdCfg<LBD, LBH, LBW>;
@@ -1069,27 +1155,35 @@ static int up_dgrad_cfg(const float* dy, const void* wp, float* dx, int N, int D
         return SIV_EINVAL;
     }
     // more than 64 KB of dynamic LDS is an opt-in
-    if (hipFuncSetAttribute((const void*)k2_up_dgrad<LBD, LBH, LBW, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)k2_up_dgrad<LBD, LBH, LBW, SPLIT, BOX>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)C::LDS_BYTES) != hipSuccess) {
         set_error("conv3d_k3_dgrad(upsampled): cannot reserve %zu bytes of LDS", C::LDS_BYTES);
         return SIV_EHIP;
     }
-    k2_up_dgrad<LBD, LBH, LBW, SPLIT><<<dim3((unsigned)nblk, (unsigned)(Cin / 64)), 256, C::LDS_BYTES, s>>>(
+    k2_up_dgrad<LBD, LBH, LBW, SPLIT, BOX><<<dim3((unsigned)nblk, (unsigned)(Cin / 64)), 256, C::LDS_BYTES, s>>>(
         dy, wp, dx, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
     SIV_CHECK_LAUNCH("conv3d_k3_dgrad(upsampled)");
     return SIV_OK;
 }
 
 // dy: [N][D][H][W][Cout] -> dx: [N][D/2][H/2][W/2][Cin]; w: the convolution's weights [Cout][27][Cin].
-// split: products from bf16 pieces.
+// split: products from bf16 pieces; force_box: the 9-tap box form whatever the volume (fp32 only).
 int k2_up_dgrad_launch(const float* dy, const float* w, float* dx, int N, int D, int H, int W, int Cin,
-                       int Cout, void* ws, size_t ws_bytes, hipStream_t s, bool split) {
+                       int Cout, void* ws, size_t ws_bytes, hipStream_t s, bool split, bool force_box) {
+    // the box form on request and from 32 K output voxels upwards (1.35x faster at the benchmark sizes);
+    // tiny volumes keep the 16-tap form
+    const bool box = !split && (force_box || (long)N * D * H * W >= (1L << 15));
     SIV_CHECK_WS(k2_up_dgrad_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3_dgrad(upsampled)");
     if (split) {
         const long total = (long)(Cin / 64) * (Cout / 8) * 64 * 2 * 64 * 2 * 8;
         long g = cdiv(total, 256);
         if (g > 4096) g = 4096;
         k2_up_pack_dgrad_b3<<<(unsigned)g, 256, 0, s>>>(w, (__bf16*)ws, Cin, Cout);
+    } else if (box) {
+        const long total = (long)(Cin / 64) * (Cout / 8) * 36 * 512;
+        long g = cdiv(total, 256);
+        if (g > 4096) g = 4096;
+        k2_up_pack_dgrad_box<<<(unsigned)g, 256, 0, s>>>(w, (float*)ws, Cin, Cout);
     } else {
         const long total = (long)(Cin / 64) * (Cout / 8) * 64 * 512;
         long g = cdiv(total, 256);
@@ -1100,6 +1194,10 @@ int k2_up_dgrad_launch(const float* dy, const float* w, float* dx, int N, int D,
     if (split) {
         if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, true>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
         return up_dgrad_cfg<4, 8, 8, true>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
+    }
+    if (box) {
+        if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, false, true>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
+        return up_dgrad_cfg<4, 8, 8, false, true>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
     }
     if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, false>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
     return up_dgrad_cfg<4, 8, 8, false>(dy, ws, dx, N, D, H, W, Cin, Cout, s);

@@ -265,10 +265,10 @@ __global__ __launch_bounds__(256) void k3_wgrad_wino2d_finish(const float* __res
         float m[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p) m[p] = 0.f;
-        for (int s = 0; s < nsets; ++s) {
-            const float* pp = part + (((long)s * ntile + tl) * 16) * 3 * 4096 + (kd * 64 + ci) * 64 + co;
+        {   // the sets have been summed into part[0] (gw_sum_sets)
+            const float* pp = part + ((long)tl * 16) * 3 * 4096 + (kd * 64 + ci) * 64 + co;
 #pragma unroll
-            for (int p = 0; p < 16; ++p) m[p] += pp[(long)p * 3 * 4096];
+            for (int p = 0; p < 16; ++p) m[p] = pp[(long)p * 3 * 4096];
         }
         // rows of A^T over ph, then over pw
         float t[3][4];
@@ -623,6 +623,9 @@ int k3_wgrad_wino2d_launch(const float* x, const float* dy, float* dw, int N, in
     k3_wgrad_wino2d<<<dim3((unsigned)(nsets * 4), (unsigned)ntile), GwCfg::NTHR, GwCfg::LDS_BYTES, s>>>(
         x, dy, (float*)ws, N, D, H, W, Cin, Cout, nrh, nrw, zsplit, nsets);
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(winograd)");
+    const long nel = (long)ntile * 48 * 4096;
+    gw_sum_sets<<<(unsigned)cdiv(nel, 256), 256, 0, s>>>((float*)ws, nsets, nel);
+    SIV_CHECK_LAUNCH("conv3d_k3_wgrad(winograd, sum)");
     const long total = (long)ntile * 3 * 4096;
     k3_wgrad_wino2d_finish<<<(unsigned)cdiv(total, 256), 256, 0, s>>>((const float*)ws, nsets, ntile, dw, Cin,
                                                                         Cout, accumulate);

@@ -74,7 +74,7 @@ int k2_up_fwd_launch(const float*, const float*, const float*, float*, int, int,
                      size_t, hipStream_t, float*, bool);
 bool k2_up_dgrad_supported(int Cin, int Cout);
 int k2_up_dgrad_launch(const float*, const float*, float*, int, int, int, int, int, int, void*, size_t,
-                       hipStream_t, bool);
+                       hipStream_t, bool, bool);
 bool k2_up_wgrad_supported(int Cin, int Cout);
 int k2_up_wgrad_launch(const float*, const float*, float*, int, int, int, int, int, int, int, void*, size_t,
                        hipStream_t);
@@ -275,7 +275,8 @@ extern "C" int siv_conv3d_k3_dgrad_up(const float* dy, const float* w, float* dx
     SIV_CHECK_ARG(k2_up_dgrad_supported(Cin, Cout),
                   "conv3d_k3_dgrad_up: needs Cin %% 64 == 0 and Cout %% 8 == 0 (got Cin=%d Cout=%d); use "
                   "siv_conv3d_k3_dgrad followed by siv_upsample2_bwd", Cin, Cout);
-    return k2_up_dgrad_launch(dy, w, dx, N, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream, conv_path() == 5);
+    return k2_up_dgrad_launch(dy, w, dx, N, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream, conv_path() == 5,
+                              conv_path() == 6);
 }
 
 extern "C" int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N,
