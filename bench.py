@@ -145,7 +145,7 @@ def main():
 
     # the layer runs through conv3d_k3_fwd_stats in training mode (convolution + BatchNorm statistics
     # in one C call: the event pair then also spans the weight-packing and the statistics-finalize
-    # launches, ~15 us of 5.8 ms) and through conv3d_k3_fwd otherwise
+    # launches, ~15 us of 4.5 ms) and through conv3d_k3_fwd otherwise
     B.conv3d_k3_fwd = timed(B.conv3d_k3_fwd)
     B.conv3d_k3_fwd_stats = timed(B.conv3d_k3_fwd_stats)
 
