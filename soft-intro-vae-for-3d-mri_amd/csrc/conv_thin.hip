@@ -276,6 +276,120 @@ __global__ __launch_bounds__(256) void c_to_one_mfma_k(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------
+// c_to_one for volumes that are long in z: a block owns an 8 x 16 (H, W) column and walks along z.
+// Every input plane of the column (10 x 18 halo voxels = 6 row tiles of 32) goes through the same small
+// GEMM as above exactly once -- the halo is re-read in the plane only, 1.4x the tensor instead of the 2.3x
+// of the 4x8x8 bricks, which is what bounds the brick kernel (L2 traffic) -- and the 27-column tap image
+// of the last three planes is kept in an LDS ring; output plane z - 1 is gathered when plane z is in.
+// ---------------------------------------------------------------------------------
+constexpr int ZW_H = 8, ZW_W = 16, ZW_HW = ZW_W + 2, ZW_HV = (ZW_H + 2) * ZW_HW;   // 180 halo voxels
+constexpr int ZW_TILES = (ZW_HV + 31) / 32;                                        // 6
+
+template <int KG>
+__global__ __launch_bounds__(256) void c_to_one_zwalk_k(const float* __restrict__ a,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ out, int N, int D, int H, int W,
+                                                        int flip, int nth, int ntw, int zsplit) {
+    constexpr int C = 8 * KG;
+    __shared__ float pim[3][ZW_HV * C1_PP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    float4 bw[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < 27) {
+            const int c = 8 * g + 4 * h;
+            if (!flip) {
+                v = *reinterpret_cast<const float4*>(w + i * C + c);
+            } else {
+                v = make_float4(w[(c + 0) * 27 + 26 - i], w[(c + 1) * 27 + 26 - i],
+                                w[(c + 2) * 27 + 26 - i], w[(c + 3) * 27 + 26 - i]);
+            }
+        }
+        bw[g] = v;
+    }
+    int b = blockIdx.x;
+    const int zp = b % zsplit; b /= zsplit;
+    const int tx = b % ntw; b /= ntw;
+    const int ty = b % nth;
+    const int n = b / nth;
+    const int zlo = (int)((long)zp * D / zsplit), zhi = (int)((long)(zp + 1) * D / zsplit);
+    const int y0 = ty * ZW_H, x0 = tx * ZW_W;
+
+    // this wave's row tiles wv and wv + 4 (the latter only for wv < 2): in-plane offset of the lane's voxel
+    int off[2];
+    bool okv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int u = (wv + 4 * q) * 32 + i;
+        const int hy = u / ZW_HW, hx = u % ZW_HW;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        okv[q] = wv + 4 * q < ZW_TILES && u < ZW_HV && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        off[q] = okv[q] ? (gy * W + gx) * C + 4 * h : 0;
+    }
+    const float* an = a + (long)n * D * H * W * C;
+    float4 av[2][KG];
+    auto load_plane = [&](int z) {
+        const bool zok = z >= 0 && z < D;
+        const float* pl = an + (long)(zok ? z : 0) * H * W * C;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int g = 0; g < KG; ++g)
+                av[q][g] = (zok && okv[q]) ? *reinterpret_cast<const float4*>(pl + off[q] + 8 * g)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    const float b0 = bias ? bias[0] : 0.f;
+    const int m = threadIdx.x;
+    const int dy = m >> 4, dx = m & 15;                 // gather: threads 0..127
+
+    load_plane(zlo - 1);
+    for (int z = zlo - 1; z <= zhi; ++z) {
+        float* pz = pim[(z + 3) % 3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (wv + 4 * q < ZW_TILES) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int g = 0; g < KG; ++g) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][g].x, bw[g].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][g].y, bw[g].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][g].z, bw[g].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][g].w, bw[g].w, acc, 0, 0, 0);
+                }
+                if (i < 27) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int u = (wv + 4 * q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (u < ZW_HV) pz[u * C1_PP + i] = acc[r];
+                    }
+                }
+            }
+        }
+        if (z < zhi) load_plane(z + 1);                 // in flight during the gather
+        __syncthreads();
+        const int zo = z - 1;
+        if (zo >= zlo && m < ZW_H * ZW_W) {
+            const int gy = y0 + dy, gx = x0 + dx;
+            if (gy < H && gx < W) {
+                float s = b0;
+#pragma unroll
+                for (int t = 0; t < 27; ++t) {
+                    const float* pp = pim[(zo + t / 9 + 2) % 3];         // plane zo - 1 + kd
+                    s += pp[((dy + (t / 3) % 3) * ZW_HW + dx + t % 3) * C1_PP + t];
+                }
+                out[(((long)n * D + zo) * H + gy) * W + gx] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // thin_wg.  Thread = (voxel lane, channel quad) with 27 (+1 for the plain sum of g) float4
 // accumulators; every block walks a contiguous range of bricks, then the voxel lanes are
 // combined through LDS and one partial row per block is written: part[block][C][28].
@@ -408,6 +522,18 @@ int k3_thin_fwd_launch(const float* a, const float* w, const float* bias, float*
     // the matrix-core kernel runs one brick per block: with several, the barrier between the GEMM and
     // the gather phase of a brick serialises what independent blocks otherwise overlap (measured)
     const unsigned grid = (unsigned)nblk;
+    if (Ca == 64 && D >= 16 && H >= 8 && W >= 16) {
+        // long volumes: z-walking columns (less halo traffic); cut along z until ~1000 blocks
+        const int nth = (H + ZW_H - 1) / ZW_H, ntw = (W + ZW_W - 1) / ZW_W;
+        int zsplit = 1;
+        while ((long)N * nth * ntw * zsplit < 900 && D / (zsplit * 2) >= 8) zsplit *= 2;
+        const long nb = (long)N * nth * ntw * zsplit;
+        if (nb <= 0x7fffffffL && (long)H * W * Ca < (1L << 30)) {
+            c_to_one_zwalk_k<8><<<(unsigned)nb, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nth, ntw, zsplit);
+            SIV_CHECK_LAUNCH("conv3d_k3(thin, z-walk)");
+            return SIV_OK;
+        }
+    }
     if (Ca == 1)
         ;
     else if (Ca == 64)

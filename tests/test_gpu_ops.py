@@ -62,6 +62,8 @@ CONV_CASES = [
     (1, 8, (8, 12, 8), 2, 1, 0), (1, 64, (9, 10, 11), 2, 1, 0), (1, 12, (6, 7, 5), 1, 1, 0),
     (8, 1, (8, 12, 8), 2, 1, 0), (64, 1, (9, 10, 11), 2, 1, 0), (16, 1, (6, 7, 5), 3, 1, 0),
     (32, 1, (8, 12, 8), 1, 1, 0), (24, 1, (6, 7, 5), 2, 1, 0), (1, 32, (5, 9, 8), 2, 1, 0), (1, 24, (6, 7, 5), 1, 1, 0),
+    # ... long enough in z for the column-walking 64 -> 1 kernel (forward, and 1 -> 64 input gradient)
+    (64, 1, (17, 9, 18), 2, 1, 0), (64, 1, (16, 8, 16), 1, 1, 0), (1, 64, (33, 12, 20), 1, 1, 0),
     # fp32 matrix-core kernels
     (8, 64, (8, 12, 8), 1, 1, 0), (64, 64, (8, 12, 8), 2, 1, 0), (64, 64, (5, 7, 9), 1, 1, 0),
     (16, 128, (10, 12, 10), 2, 1, 0), (128, 64, (4, 8, 8), 1, 1, 0), (64, 128, (3, 5, 17), 1, 1, 0),
