@@ -15,8 +15,8 @@
 //
 // The transformed input V[pos][plane][tile][ci] of one 8-channel chunk takes 72 KB of LDS, so one block
 // runs per CU and nothing else would cover its barriers: V is double buffered.  While the waves multiply
-// chunk c out of one buffer, six of the eight waves fetch the 4x4 patches of chunk c+1 from global memory
-// into registers (overlapping patches: L1/L2 hits), transform them and fill the other buffer; one barrier
+// chunk c out of one buffer, six of the eight waves transform the 4x4 patches of chunk c+1 (fetched into
+// registers at the end of chunk c-1; overlapping patches: L1/L2 hits) and fill the other buffer; one barrier
 // per chunk.  The output transform along W is done on the accumulators, the one along H needs the four
 // waves ph = 0..3 and goes through LDS together with the transposition for 16-byte stores.
 #include "siv_common.h"
@@ -26,9 +26,6 @@
 // 4 = no weight-fragment loads, 8 = no LDS fragment reads, 64 = no epilogue, 128 = no first patch loads
 #ifndef SIV_W2EXP
 #define SIV_W2EXP 0
-#endif
-#ifndef SIV_W2LATE
-#define SIV_W2LATE 1
 #endif
 
 namespace siv {
@@ -172,9 +169,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
 #pragma unroll
         for (int piece = 0; piece < 8; ++piece) stage_piece(piece, lds);
     }
-#if SIV_W2LATE
     if (!(SIV_W2EXP & 17)) load_patch((nchunk > 1 ? 1 : 0) * C::CK);
-#endif
     __syncthreads();
 
     for (int cc = 0; cc < nchunk; ++cc) {
@@ -184,9 +179,6 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
         // every wave issues the patch loads (waves 6 and 7 re-read voxel 0 and drop it): with one
         // instruction stream the compiler counts the loads that may stay in flight at each wait
         // instead of assuming, at the first tap, the path that issued none
-#if !SIV_W2LATE
-        if (!(SIV_W2EXP & 17)) load_patch((more ? cc + 1 : cc) * C::CK);
-#endif
         const float* wc = wlane + (long)cc * C::TAPS * C::SLICE;
         float4 anext[2];
 #pragma unroll
@@ -229,11 +221,9 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
                 if (t >= 8) stage_piece(t - 4, nxt);
             }
         }
-#if SIV_W2LATE
         // the patch of the chunk after next goes out right behind the last pieces of this one: its
         // issue overlaps the wait at the barrier and it has a chunk and a half to arrive
         if (!(SIV_W2EXP & 17)) load_patch((cc + 2 < nchunk ? cc + 2 : cc) * C::CK);
-#endif
         if (!(SIV_W2EXP & 2)) __syncthreads();
     }
 
