@@ -248,6 +248,43 @@ def test_split_bf16_path_step_matches_fp32_path():
         np.testing.assert_allclose(float(res[5][1][k].norm()), float(g3.norm()), rtol=2e-2, err_msg=k)
 
 
+def test_large_volume_kernels_step_matches_direct_kernels():
+    """One full E+D iteration of the 64-128 channel model at 48x48x48, batch 2 -- large enough for the
+    automatic dispatch (path 0) to pick every large-volume kernel: Winograd F(2x2,3x3) forward / input
+    gradient, Winograd weight gradients (plain and upsampled), the box-form upsampled input gradient and
+    the column-walking 64 -> 1 kernel -- against the same iteration on the direct matrix-core kernels
+    (path 4).  Loss terms to 1e-4 relative, gradient norms per parameter to 2 % (exact fp32 arithmetic
+    on both sides; only the order of the additions differs)."""
+    import siv.backend as sb
+    import siv.models.models as models
+    dims, Bn = (48, 48, 48), 2
+    gen = torch.Generator().manual_seed(26)
+    real = torch.rand(Bn, 1, *dims, generator=gen)
+    noise = torch.randn(Bn, 1, 12, 12, 12, generator=gen)
+    hp = O.Hyper(dims=dims)
+    res = {}
+    for path in (4, 0):
+        torch.manual_seed(25)
+        net = models.SoftIntroVAE(*WIDE)
+        with torch.no_grad():
+            for m in net.modules():
+                if type(m) == torch.nn.Conv3d:
+                    torch.nn.init.kaiming_normal_(m.weight, nonlinearity="leaky_relu")
+        net = net.to("cuda").train()
+        sb.get_backend().set_conv_path(path)
+        try:
+            (st, grads), = _run_steps(net, lambda s: (real, noise), hp, O.Draws(seed=27), 1)
+        finally:
+            sb.get_backend().set_conv_path(0)
+        res[path] = (st, grads)
+    for k in ("lossE", "lossD", "kl_real", "fake_kl", "rec_kl", "loss_rec"):
+        np.testing.assert_allclose(res[0][0][k], res[4][0][k], rtol=1e-4, err_msg=k)
+    for k, g4 in res[4][1].items():
+        if k.endswith(BN_CANCELLED) or float(g4.norm()) == 0.0:
+            continue
+        np.testing.assert_allclose(float(res[0][1][k].norm()), float(g4.norm()), rtol=2e-2, err_msg=k)
+
+
 def test_eval_forward_wide_matches_oracle():
     import siv.models.models as models
     torch.manual_seed(8)
