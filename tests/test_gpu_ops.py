@@ -141,22 +141,22 @@ def test_conv3d_k3_fwd_dgrad_wgrad(B, cin, cout, dims, n, ups, path):
     assert y.is_contiguous(memory_format=torch.channels_last_3d)
 
 
-@pytest.mark.parametrize("path", [0, 6])
-def test_conv_wgrad_accumulates(B, path):
+@pytest.mark.parametrize("path,ups", [(0, 1), (6, 1), (0, 2), (6, 2)])
+def test_conv_wgrad_accumulates(B, path, ups):
     """accumulate = 1 adds to dw / dbias instead of overwriting them (C-ABI call)."""
     import siv._lib as L
-    from siv.backend import cl, empty_cl, _p
+    from siv.backend import cl, _p
     gen = torch.Generator().manual_seed(11)
-    x = cl(dev(rnd(gen, 2, 64, 6, 8, 8)))
+    x = cl(dev(rnd(gen, 2, 64, 6 // ups, 8 // ups, 8 // ups)))
     dy = cl(dev(rnd(gen, 2, 64, 6, 8, 8)))
     base = cl(dev(rnd(gen, 64, 64, 3, 3, 3)))
     bias0 = dev(rnd(gen, 64))
     B.set_conv_path(path)
     try:
-        dw_ref, db_ref = B.conv3d_k3_wgrad(x, dy, 1, True)
+        dw_ref, db_ref = B.conv3d_k3_wgrad(x, dy, ups, True)
         dw, db = base.clone(memory_format=torch.preserve_format), bias0.clone()
         ws, wsb = B._workspace(dy)
-        L.check(B.lib.siv_conv3d_k3_wgrad(_p(x), _p(dy), _p(dw), _p(db), 2, 6, 8, 8, 64, 64, 1, 1, ws, wsb,
+        L.check(B.lib.siv_conv3d_k3_wgrad(_p(x), _p(dy), _p(dw), _p(db), 2, 6, 8, 8, 64, 64, ups, 1, ws, wsb,
                                           B._stream(dy)), "siv_conv3d_k3_wgrad")
     finally:
         B.set_conv_path(0)
