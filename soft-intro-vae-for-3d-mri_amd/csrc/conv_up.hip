@@ -30,7 +30,7 @@ struct UpCfg {
     static constexpr int LBD = LBD_, LBH = LBH_, LBW = LBW_;
     static constexpr int CK = 8, CKP = 12;
     static constexpr int M = LBD * LBH * LBW;             // rows in use (<= 128)
-    static constexpr int WM = 2, WN = 2, NW = 4, NTHR = 256, NT = 64, AM = 2;
+    static constexpr int WM = 2, WN = 2, NW = 4, NTHR = 256, NT = 64, AM = (M + 63) / 64;
     static constexpr int HD = LBD + 1, HH = LBH + 2, HW = LBW + 2;
     static constexpr int HV = HD * HH * HW;               // halo voxels
     static constexpr int NH = (HV * 2 + NTHR - 1) / NTHR; // float4 halo items per thread and chunk
@@ -40,17 +40,18 @@ struct UpCfg {
     static constexpr int EPI_STRIDE = 40, EPI_FLOATS = 32 * EPI_STRIDE;
     static constexpr int LDS_FLOATS = V_FLOATS > NW * EPI_FLOATS ? V_FLOATS : NW * EPI_FLOATS;
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
-    static_assert(M <= 128 && M > 96, "two row tiles per wave, two waves along M");
+    static_assert(M <= 128 && M > 32, "one or two row tiles per wave, two waves along M");
 };
 
 // Epilogue shared by the two forward kernels: per row tile and parity class, transpose the 32x32 result
 // through this wave's slice of LDS and write 16-byte channel runs.  When stat_part is given the block also
 // emits, per output channel, the sum and the sum of squares of its (bias-free) outputs.
-template <int LBD, int LBH, int LBW>
-__device__ __forceinline__ void up_fwd_store(f32x16 (&acc)[4][2], float* lds, const float* __restrict__ bias,
+template <int LBD, int LBH, int LBW, int AMX>
+__device__ __forceinline__ void up_fwd_store(f32x16 (&acc)[4][AMX], float* lds, const float* __restrict__ bias,
                                              float* __restrict__ y, float* __restrict__ stat_part, int n, int z0,
                                              int y0, int x0, int ad, int co0, int D, int H, int W, int Cout) {
     using C = UpCfg<LBD, LBH, LBW>;
+    static_assert(AMX == C::AM, "accumulator sets per wave");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -284,6 +285,175 @@ __global__ __launch_bounds__(256) void k2_up_pack_weights(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------
+// The same convolution in product form over (H, W).  Along one axis the two outputs of a
+// low-resolution voxel j are
+//   y[2j]   = w0 x[j-1] + (w1 + w2) x[j] = w0 (x[j-1] - x[j]) + S x[j]
+//   y[2j+1] = (w0 + w1) x[j] + w2 x[j+1] = w2 (x[j+1] - x[j]) + S x[j],      S = w0 + w1 + w2
+// i.e. three products (P-, P0, P+) for two outputs.  Over (H, W) that is 9 products per
+// low-resolution voxel instead of 16, with the z axis collapsed as before (2 taps per D parity):
+// 18 multiply-adds per 4 outputs instead of 32.  The differences are formed from the raw halo while
+// the operand is fetched (nine LDS reads and twelve subtractions per row tile and plane feed 36
+// matrix instructions); the nine accumulator sets are folded into the four parity outputs in the
+// epilogue: y[ah][aw] = P[s(ah)][s(aw)] + P[s(ah)][0] + P[0][s(aw)] + P[0][0].
+// One row tile per wave (64-row bricks): 9 x 16 accumulator registers.
+// wp: see k2_up_pack_weights_prod.
+// ---------------------------------------------------------------------------------
+template <int LBD, int LBH, int LBW>
+__global__ __launch_bounds__(256, 2) void k2_up_fwd_prod(const float* __restrict__ x,
+                                                         const float* __restrict__ wp,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ y, int N, int D, int H, int W,
+                                                         int Cin, int Cout, int nbd, int nbh, int nbw,
+                                                         float* __restrict__ stat_part) {
+    using C = UpCfg<LBD, LBH, LBW>;
+    static_assert(C::AM == 1, "one row tile per wave");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    const int ad = b & 1; b >>= 1;
+    const int bx = b % nbw; b /= nbw;
+    const int by = b % nbh; b /= nbh;
+    const int bz = b % nbd;
+    const int n = b / nbd;
+    const int z0 = bz * LBD, y0 = by * LBH, x0 = bx * LBW;
+    const int co0 = blockIdx.y * C::NT;
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
+    const int nchunk = Cin / C::CK;
+
+    f32x16 acc[9];             // [ph * 3 + pw], p = 0, 1, 2 standing for (-, 0, +)
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+
+    int m = wm * 32 + li;
+    if (m >= C::M) m = 0;
+    const int aoff = (((m / (LBH * LBW)) * C::HH + (m / LBW) % LBH) * C::HW + m % LBW) * C::CKP + 4 * lh;
+    constexpr int NTAP = 18, PD = 3;
+    const float* wlane = wp + ((long)(blockIdx.y * 2 + ad) * nchunk) * NTAP * C::SLICE + (wn * 32 + li) * 8 + 4 * lh;
+    float4 bring[PD];
+
+    float4 hreg[C::NH];
+    long hoff[C::NH];
+    unsigned hmask = 0;
+#pragma unroll
+    for (int i = 0; i < C::NH; ++i) {
+        const int idx = tid + C::NTHR * i;
+        const int hv = idx >> 1, q = idx & 1;
+        const int hx = hv % C::HW, hy = (hv / C::HW) % C::HH, hz = hv / (C::HW * C::HH);
+        const int gz = z0 + ad - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = hv < C::HV && gz >= 0 && gz < Dl && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl;
+        hoff[i] = ok ? ((((long)n * Dl + gz) * Hl + gy) * Wl + gx) * Cin + 4 * q : 0;
+        hmask |= (unsigned)ok << i;
+    }
+    auto load_halo = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < C::NH; ++i) hreg[i] = *reinterpret_cast<const float4*>(x + hoff[i] + c0);
+    };
+    load_halo(0);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) bring[i] = *reinterpret_cast<const float4*>(wlane + i * C::SLICE);
+#define SIV_PIN(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
+#pragma unroll
+    for (int i = 0; i < C::NH; ++i) SIV_PIN(hreg[i]);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) SIV_PIN(bring[i]);
+#undef SIV_PIN
+
+    auto sub4 = [](float4 a, float4 c) { return make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w); };
+    for (int cc = 0; cc < nchunk; ++cc) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < C::NH; ++i) {
+            const int idx = tid + C::NTHR * i;
+            if (!((hmask >> i) & 1)) hreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((idx >> 1) < C::HV)
+                *reinterpret_cast<float4*>(lds + (idx >> 1) * C::CKP + 4 * (idx & 1)) = hreg[i];
+        }
+        __syncthreads();
+        load_halo((cc + 1 < nchunk ? cc + 1 : cc) * C::CK);
+        const float* wc = wlane + (long)cc * NTAP * C::SLICE;
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd) {
+            // 3x3 neighbourhood of the row's voxel in plane sd, differences along W, then along H
+            float4 d[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float* row = lds + aoff + ((sd * C::HH + r) * C::HW) * C::CKP;
+                const float4 c0 = *reinterpret_cast<const float4*>(row);
+                const float4 c1 = *reinterpret_cast<const float4*>(row + C::CKP);
+                const float4 c2 = *reinterpret_cast<const float4*>(row + 2 * C::CKP);
+                d[r][0] = sub4(c0, c1);
+                d[r][1] = c1;
+                d[r][2] = sub4(c2, c1);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ph = t / 3, pw = t % 3, tt = sd * 9 + t;
+                const float4 av = ph == 0 ? sub4(d[0][pw], d[1][pw]) : ph == 1 ? d[1][pw] : sub4(d[2][pw], d[1][pw]);
+                const float4 bv = bring[tt % PD];
+                bring[tt % PD] = *reinterpret_cast<const float4*>(wc + (tt + PD) * C::SLICE);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // fold the nine product sets into the four (H, W) parity outputs
+    f32x16 out4[4][1];
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+        const int sh = (pos >> 1) ? 2 : 0, sw = (pos & 1) ? 2 : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            out4[pos][0][r] = (acc[sh * 3 + sw][r] + acc[sh * 3 + 1][r]) + (acc[3 + sw][r] + acc[4][r]);
+    }
+    up_fwd_store<LBD, LBH, LBW>(out4, lds, bias, y, stat_part, n, z0, y0, x0, ad, co0, D, H, W, Cout);
+}
+
+// Weights of the product form: wp[ct][ad][cc][t = sd * 9 + ph * 3 + pw][co (64)][ci (8)] = sum over the
+// taps kd that collapse onto (ad, sd) and over kh in T(ph), kw in T(pw) of w[co][kd][kh][kw][ci], with
+// T(-) = {0}, T(0) = {0, 1, 2}, T(+) = {2}; zero padded in co.
+__global__ __launch_bounds__(256) void k2_up_pack_weights_prod(const float* __restrict__ w,
+                                                               float* __restrict__ wp, int Kin, int Kout) {
+    const int nchunk = Kin / 8, ntile = (Kout + 63) / 64;
+    const long total = (long)ntile * 2 * nchunk * 18 * 64 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        long r = i >> 3;
+        const int co = (int)(r & 63); r >>= 6;
+        const int t = (int)(r % 18); r /= 18;
+        const int cc = (int)(r % nchunk); r /= nchunk;
+        const int ad = (int)(r & 1);
+        const int ct = (int)(r >> 1);
+        const int sd = t / 9, ph = (t % 9) / 3, pw = t % 3;
+        const int kco = ct * 64 + co, kci = cc * 8 + j;
+        float v = 0.f;
+        if (kco < Kout) {
+            int d0, d1;
+            collapsed_range(ad, sd, d0, d1);
+            const int h0 = ph == 2 ? 2 : 0, h1 = ph == 0 ? 0 : 2;
+            const int w0 = pw == 2 ? 2 : 0, w1 = pw == 0 ? 0 : 2;
+            for (int kd = d0; kd <= d1; ++kd)
+                for (int kh = h0; kh <= h1; ++kh)
+                    for (int kw = w0; kw <= w1; ++kw) v += w[((long)kco * 27 + (kd * 3 + kh) * 3 + kw) * Kin + kci];
+        }
+        wp[i] = v;
+    }
+}
+
 // The same convolution with every fp32 product formed from three bf16 pieces per operand on the bf16
 // matrix cores (scheme and operand packing: conv_wino_b3.hip).  The staged halo holds [h | m | l] pieces
 // of 8 channels per voxel (48 bytes, the fp32 footprint); wp: see k2_up_pack_weights_b3.
@@ -468,9 +638,33 @@ size_t k2_up_fwd_ws_bytes(int Cin, int Cout) {
     return ((size_t)(Cout / 64) * 2 * (Cin / 8) * 32 + 4) * 4096;
 }
 // number of [2][Cout] partial-statistics rows the kernel emits (D, H, W: output extents)
-long k2_up_fwd_blocks(int N, int D, int H, int W) {
+// the product form from 32 K output voxels upwards (and on request); its bricks hold one low-resolution plane
+static bool up_use_prod(int N, int D, int H, int W, bool split, bool force) {
+    return !split && (force || (long)N * D * H * W >= (1L << 15));
+}
+long k2_up_fwd_blocks(int N, int D, int H, int W, bool split, bool force_prod) {
+    if (up_use_prod(N, D, H, W, split, force_prod)) {
+        if (up_wide10(W)) return (long)N * (D / 2) * cdiv(H / 2, 6) * cdiv(W / 2, 10) * 2;
+        return (long)N * (D / 2) * cdiv(H / 2, 8) * cdiv(W / 2, 8) * 2;
+    }
     if (up_wide10(W)) return (long)N * (D / 2) * cdiv(H / 2, 12) * cdiv(W / 2, 10) * 2;
     return (long)N * cdiv(D / 2, 2) * cdiv(H / 2, 8) * cdiv(W / 2, 8) * 2;
+}
+
+template <int LBD, int LBH, int LBW>
+static int up_launch_prod(const float* x, const void* wp, const float* bias, float* y, int N, int D, int H,
+                          int W, int Cin, int Cout, hipStream_t s, float* stat_part) {
+    using C = UpCfg<LBD, LBH, LBW>;
+    const int nbd = (int)cdiv(D / 2, LBD), nbh = (int)cdiv(H / 2, LBH), nbw = (int)cdiv(W / 2, LBW);
+    const long nblk = (long)N * nbd * nbh * nbw * 2;
+    if (nblk > 0x7fffffffL) {
+        set_error("conv3d_k3(upsampled): too many bricks");
+        return SIV_EINVAL;
+    }
+    k2_up_fwd_prod<LBD, LBH, LBW><<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 256, C::LDS_BYTES, s>>>(
+        x, (const float*)wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part);
+    SIV_CHECK_LAUNCH("conv3d_k3(upsampled, product form)");
+    return SIV_OK;
 }
 
 template <int LBD, int LBH, int LBW>
@@ -499,8 +693,17 @@ static int up_launch_cfg(const float* x, const void* wp, const float* bias, floa
 // overlap the first k2_up_fwd_ws_bytes() bytes of ws.  split: products from bf16 pieces.
 int k2_up_fwd_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H,
                      int W, int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t s, float* stat_part,
-                     bool split) {
+                     bool split, bool force_prod) {
     SIV_CHECK_WS(k2_up_fwd_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(upsampled)");
+    if (up_use_prod(N, D, H, W, split, force_prod)) {
+        const long total = (long)(Cout / 64) * 2 * (Cin / 8) * 18 * 512;
+        long g = cdiv(total, 256);
+        if (g > 4096) g = 4096;
+        k2_up_pack_weights_prod<<<(unsigned)g, 256, 0, s>>>(w, (float*)ws, Cin, Cout);
+        SIV_CHECK_LAUNCH("conv3d_k3(pack upsampled weights, product form)");
+        if (up_wide10(W)) return up_launch_prod<1, 6, 10>(x, ws, bias, y, N, D, H, W, Cin, Cout, s, stat_part);
+        return up_launch_prod<1, 8, 8>(x, ws, bias, y, N, D, H, W, Cin, Cout, s, stat_part);
+    }
     if (split) {
         const long total = (long)(Cout / 64) * 2 * (Cin / 8) * 32 * 2 * 64 * 2 * 8;
         long g = cdiv(total, 256);

@@ -69,9 +69,9 @@ int k3_fwd_wino_b3_launch(const float*, const float*, const float*, float*, int,
 // conv_up.hip
 bool k2_up_fwd_supported(int Cin, int Cout);
 size_t k2_up_fwd_ws_bytes(int Cin, int Cout);
-long k2_up_fwd_blocks(int N, int D, int H, int W);
+long k2_up_fwd_blocks(int N, int D, int H, int W, bool split, bool force_prod);
 int k2_up_fwd_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int, void*,
-                     size_t, hipStream_t, float*, bool);
+                     size_t, hipStream_t, float*, bool, bool);
 bool k2_up_dgrad_supported(int Cin, int Cout);
 int k2_up_dgrad_launch(const float*, const float*, float*, int, int, int, int, int, int, void*, size_t,
                        hipStream_t, bool, bool);
@@ -172,7 +172,7 @@ extern "C" int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bi
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
         return k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s);
     if (use_up(path, al, ups, Cin, Cout))
-        return k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, nullptr, path == 5);
+        return k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, nullptr, path == 5, path == 6);
     if (use_b3(path, al, ups, Cin, Cout))
         return k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, nullptr);
     if (use_w2d(path, al, ups, N, D, H, W, Cin, Cout))
@@ -207,7 +207,7 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
     size_t wbytes = 0;
     long nblk = 0;
     if (use_up(path, al, ups, Cin, Cout)) {
-        fused = UP, wbytes = k2_up_fwd_ws_bytes(Cin, Cout), nblk = k2_up_fwd_blocks(N, D, H, W);
+        fused = UP, wbytes = k2_up_fwd_ws_bytes(Cin, Cout), nblk = k2_up_fwd_blocks(N, D, H, W, path == 5, path == 6);
     } else if (use_b3(path, al, ups, Cin, Cout)) {
         fused = B3, wbytes = k3_fwd_wino_b3_ws_bytes(Cin, Cout), nblk = k3_fwd_wino_bricks(N, D, H, W);
     } else if (use_w2d(path, al, ups, N, D, H, W, Cin, Cout)) {
@@ -220,7 +220,7 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
         SIV_CHECK_WS(wbytes + (size_t)nblk * 2 * Cout * sizeof(float), ws_bytes, "conv3d_k3_fwd_bnstats");
         float* part = (float*)((char*)ws + wbytes);
         switch (fused) {
-        case UP: rc = k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, part, path == 5); break;
+        case UP: rc = k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, part, path == 5, path == 6); break;
         case B3: rc = k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part); break;
         case W2D: rc = k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part); break;
         default: rc = k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s, part); break;

@@ -104,6 +104,10 @@ CONV_CASES = [
     # extents, partial columns, two channel tiles, columns cut along z
     (64, 64, (8, 12, 8), 2, 2, 6), (128, 64, (8, 8, 16), 1, 2, 6), (64, 128, (4, 24, 40), 1, 2, 6),
     (64, 64, (2, 2, 2), 1, 2, 6), (64, 64, (20, 8, 8), 1, 2, 6), (64, 64, (6, 10, 14), 3, 2, 6),
+    # ... and the product form of the upsampled forward (Cin % 8 == 0, Cout % 64 == 0): odd low-resolution
+    # extents, 10- and 20-wide low-resolution volumes, three samples
+    (8, 64, (6, 10, 14), 2, 2, 6), (16, 64, (6, 26, 18), 1, 2, 6), (24, 64, (2, 2, 2), 3, 2, 6),
+    (64, 128, (4, 24, 40), 1, 2, 6), (16, 64, (10, 24, 20), 1, 2, 6),
     # the same wide shapes through the generic kernels (cross-check of the dispatcher)
     (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
 ]
@@ -438,6 +442,8 @@ def test_add_act(B, shape):
     (64, 64, (8, 12, 8), 2, 1, 5, False), (8, 64, (5, 7, 9), 3, 1, 5, True),   # ... and the split-bf16 kernels
     (64, 128, (8, 8, 16), 1, 2, 5, True), (16, 64, (10, 24, 20), 1, 2, 5, False),
     (64, 64, (8, 12, 8), 2, 1, 6, False), (8, 64, (5, 7, 9), 3, 1, 6, True), (16, 128, (10, 24, 20), 1, 1, 6, True),
+    # ... and the product form of the upsampled kernel (forced by path 6; one-plane bricks, 20-wide variant)
+    (64, 128, (8, 8, 16), 1, 2, 6, True), (16, 64, (10, 24, 20), 1, 2, 6, False), (8, 64, (6, 10, 14), 2, 2, 6, True),
     (4, 8, (6, 7, 5), 2, 1, 0, True), (1, 8, (8, 12, 8), 2, 1, 0, True), (64, 64, (10, 12, 10), 1, 1, 0, False),
 ])
 def test_conv_fwd_with_bn_statistics(B, cin, cout, dims, n, ups, path, use_bias):
