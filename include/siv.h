@@ -43,15 +43,15 @@ int siv_version(void);
 /* Upper bound on the scratch any entry point needs for tensors up to the given size. */
 size_t siv_workspace_bytes(void);
 /* Kernel-path override: 0 = automatic (Winograd F(2x2,3x3) forward / input gradient and F(3x3,2x2)
- * weight gradient for large non-upsampled layers; behind an upsample collapsed taps forward, their
- * box form for the input gradient and the Winograd weight gradient; direct matrix-core kernels
+ * weight gradient for large non-upsampled layers; behind an upsample collapsed taps (in product form forward,
+ * box form for the input gradient) and the Winograd weight gradient; direct matrix-core kernels
  * elsewhere), 1 = force the generic (any-shape)
  * kernels, 2 = force the specialised kernels (error when the shape has none), 3 = Winograd F(2,3)
  * along W wherever it is supported, 4 = matrix-core kernels without Winograd, 5 = as 0, but the
  * forward / input-gradient convolutions with Cin % 8 == 0 and Cout % 64 == 0 form their fp32
  * products from three bf16 pieces per operand on the bf16 matrix cores (fp32 accumulate; error of
  * the order of fp32 rounding, not bf16; opt-in), 6 = the large-volume kernels of path 0 (two-dimensional Winograd forward, input gradient and
- * weight gradient, box-form upsampled input gradient) wherever they are supported, whatever the volume. */
+ * weight gradient, product-form / box-form upsampled forward / input gradient) wherever they are supported, whatever the volume. */
 int siv_set_conv_path(int path);
 
 /* ---- 3x3x3 convolution, stride 1, zero padding 1 --------------------------------
