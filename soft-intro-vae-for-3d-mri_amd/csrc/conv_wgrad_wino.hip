@@ -46,6 +46,7 @@ struct GwCfg {
 
 struct GwGeom {
     int N, D, H, W, nrh, nrw, zsplit, nsets;
+    int tpr;        // tiles per row of a column: 4 (8 x 8 voxels, 16 tiles) or 5 (6 x 10 voxels, 15 tiles)
 };
 
 // The work of one wave over all items of its block.  ISV: the wave stages x (4x4 patch, two rows of it
@@ -61,7 +62,9 @@ __device__ __forceinline__ void gw_run(const float* __restrict__ src, const int 
                                        const int aoff, const int boff, const int cg, const int tile) {
     using C = GwCfg;
     constexpr int NC = ISV ? 4 : 2;
-    const int th = tile >> 2, tw = tile & 3;
+    const int th = tile / g.tpr, tw = tile - th * g.tpr;
+    const bool tile_ok = th < 16 / g.tpr;                                 // slot 15 is empty with 5 tiles per row
+    const int colh = 2 * (16 / g.tpr), colw = 2 * g.tpr;                  // voxels of a column: 8 x 8 or 6 x 10
     const int soff = (4 * cg) * C::CS + tile;                          // + position * 64 * CS + e * CS
     const int rA = ISV ? ph : (ph == 3 ? 1 : 0);
     const int rB = ISV ? (ph <= 1 ? 2 : 1) : (ph == 0 ? 0 : 1);
@@ -121,8 +124,8 @@ __device__ __forceinline__ void gw_run(const float* __restrict__ src, const int 
         if (zlo >= zhi) continue;
 
         // offsets and coefficients of this item's 2 x NC voxels
-        const int gy0 = ry * C::RH + 2 * th + (ISV ? -1 : 0), gx0 = rx * C::RW + 2 * tw + (ISV ? -1 : 0);
-        const bool okA = gy0 + rA >= 0 && gy0 + rA < g.H, okB = gy0 + rB >= 0 && gy0 + rB < g.H;
+        const int gy0 = ry * colh + 2 * th + (ISV ? -1 : 0), gx0 = rx * colw + 2 * tw + (ISV ? -1 : 0);
+        const bool okA = tile_ok && gy0 + rA >= 0 && gy0 + rA < g.H, okB = tile_ok && gy0 + rB >= 0 && gy0 + rB < g.H;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const bool okx = gx0 + c >= 0 && gx0 + c < g.W;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void k3_wgrad_wino2d(const float* __restric
                                                           const float* __restrict__ dy,
                                                           float* __restrict__ part, int N, int D, int H, int W,
                                                           int Cin, int Cout, int nrh, int nrw, int zsplit,
-                                                          int nsets) {
+                                                          int nsets, int tpr) {
     using C = GwCfg;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void k3_wgrad_wino2d(const float* __restric
     // staging item: (tile, group of four channels); waves 0..3: x, waves 4..7: dy
     const int st = tid & 255;
     const int cg = st & 15, tile = st >> 4;
-    const GwGeom g = {N, D, H, W, nrh, nrw, zsplit, nsets};
+    const GwGeom g = {N, D, H, W, nrh, nrw, zsplit, nsets, tpr};
     if (wave < 4) gw_run<true>(x + cit * 64 + 4 * cg, Cin, acc, lds, ph, set, g, aoff, boff, cg, tile);
     else gw_run<false>(dy + cot * 64 + 4 * cg, Cout, acc, lds, ph, set, g, aoff, boff, cg, tile);
 
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void k2_up_wgrad_wino(const float* __restri
     const int boff = (coh * 32 + li) * C::CS + 4 * lh;
     const int st = tid & 255;
     const int cg = st & 15, tile = st >> 4;
-    const GwGeom g = {N, D, H, W, nrh, nrw, zsplit, nsets};
+    const GwGeom g = {N, D, H, W, nrh, nrw, zsplit, nsets, 4};
     if (wave < 4) gu_run<true>(x + cit * 64 + 4 * cg, Cin, acc, lds, phi, set, g, aoff, boff, zt, cg, tile);
     else gu_run<false>(dy + cot * 64 + 4 * cg, Cout, acc, lds, phi, set, g, aoff, boff, zt, cg, tile);
 
@@ -605,7 +608,11 @@ int k3_wgrad_wino2d_launch(const float* x, const float* dy, float* dw, int N, in
                   "conv3d_k3_wgrad(winograd): plane too large for 32-bit offsets");
     const int ntile = (Cin / 64) * (Cout / 64);
     const int nsets = gw_nsets(Cin, Cout);
-    const int nrh = (H + 7) / 8, nrw = (W + 7) / 8;
+    // 6 x 10-voxel columns (15 tiles) where they cover the plane with less padding than 8 x 8 ones
+    // (10-, 20-wide levels of an 80 x 96 x 80 volume)
+    const long pad8 = cdiv(H, 8) * 8 * cdiv(W, 8) * 8, pad10 = cdiv(H, 6) * 6 * cdiv(W, 10) * 10;
+    const int tpr = pad10 * 16 < pad8 * 15 ? 5 : 4;
+    const int nrh = tpr == 5 ? (int)cdiv(H, 6) : (H + 7) / 8, nrw = tpr == 5 ? (int)cdiv(W, 10) : (W + 7) / 8;
     // cut the columns along z until every set has at least a dozen items (load balance), while the
     // pieces stay long enough to amortise their pipeline fill
     const long ncol = (long)N * nrh * nrw;
@@ -621,7 +628,7 @@ int k3_wgrad_wino2d_launch(const float* x, const float* dy, float* dw, int N, in
         return SIV_EHIP;
     }
     k3_wgrad_wino2d<<<dim3((unsigned)(nsets * 4), (unsigned)ntile), GwCfg::NTHR, GwCfg::LDS_BYTES, s>>>(
-        x, dy, (float*)ws, N, D, H, W, Cin, Cout, nrh, nrw, zsplit, nsets);
+        x, dy, (float*)ws, N, D, H, W, Cin, Cout, nrh, nrw, zsplit, nsets, tpr);
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(winograd)");
     const long nel = (long)ntile * 48 * 4096;
     gw_sum_sets<<<(unsigned)cdiv(nel, 256), 256, 0, s>>>((float*)ws, nsets, nel);

@@ -132,8 +132,10 @@ static bool use_gw(int path, bool aligned, int ups, int N, int D, int H, int W, 
     if ((long)H * W * (Cin > Cout ? Cin : Cout) >= (1L << 29)) return false;
     if (path == 6) return true;
     if (path != 0 && path != 5) return false;
-    const long nrh = (H + 7) / 8, nrw = (W + 7) / 8;
-    return (long)N * nrh * nrw * (D / ups) >= 256 && 100L * H * W >= 45L * nrh * nrw * 64;
+    // columns of 8 x 8 voxels, or (non-upsampled kernel) of 6 x 10 where those pad less
+    long nrh = (H + 7) / 8, nrw = (W + 7) / 8, colv = 64;
+    if (ups == 1 && cdiv(H, 6) * cdiv(W, 10) * 60 * 16 < nrh * nrw * 64 * 15) nrh = cdiv(H, 6), nrw = cdiv(W, 10), colv = 60;
+    return (long)N * nrh * nrw * (D / ups) >= 256 && 100L * H * W >= 45L * nrh * nrw * colv;
 }
 
 // Path 5: the Winograd kernel whose fp32 products are formed from bf16 triples on the bf16 matrix cores

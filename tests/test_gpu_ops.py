@@ -100,6 +100,8 @@ CONV_CASES = [
     # channel tiles, columns cut along z (D = 40 with one column)
     (128, 64, (9, 10, 12), 1, 1, 6), (128, 128, (6, 12, 20), 2, 1, 6), (64, 64, (17, 8, 24), 3, 1, 6),
     (256, 256, (2, 4, 8), 1, 1, 6), (64, 64, (40, 8, 8), 1, 1, 6), (64, 192, (3, 9, 9), 2, 1, 6),
+    # ... with 6 x 10-voxel columns (10- and 20-wide planes), partial columns included
+    (64, 64, (10, 12, 10), 2, 1, 6), (128, 64, (5, 13, 20), 1, 1, 6), (64, 128, (20, 7, 30), 1, 1, 6),
     # ... and its form for an upsampled input (3x3 live positions, z planes paired): odd low-resolution
     # extents, partial columns, two channel tiles, columns cut along z
     (64, 64, (8, 12, 8), 2, 2, 6), (128, 64, (8, 8, 16), 1, 2, 6), (64, 128, (4, 24, 40), 1, 2, 6),
