@@ -125,8 +125,8 @@ static bool use_w2d(int path, bool aligned, int ups, int N, int D, int H, int W,
 }
 
 // Winograd F(3x3,2x2) weight gradient: on request (path 6) and automatically where it was measured
-// faster than the direct kernel (1.85-2.15x from 20x24x20 upwards at batch 8, 1.1x at 10x12x10): enough
-// column steps to keep its 256 blocks busy, planes that fill at least 45 % of their 8x8 columns
+// faster than the direct kernel (1.9-2.2x from 10x12x10 upwards at batch 8): at least 128 column steps
+// for its 256 persistent blocks, planes that fill at least 45 % of their columns
 static bool use_gw(int path, bool aligned, int ups, int N, int D, int H, int W, int Cin, int Cout) {
     if (!aligned || !k3_wgrad_wino2d_supported(Cin, Cout)) return false;
     if ((long)H * W * (Cin > Cout ? Cin : Cout) >= (1L << 29)) return false;
@@ -135,7 +135,7 @@ static bool use_gw(int path, bool aligned, int ups, int N, int D, int H, int W, 
     // columns of 8 x 8 voxels, or (non-upsampled kernel) of 6 x 10 where those pad less
     long nrh = (H + 7) / 8, nrw = (W + 7) / 8, colv = 64;
     if (ups == 1 && cdiv(H, 6) * cdiv(W, 10) * 60 * 16 < nrh * nrw * 64 * 15) nrh = cdiv(H, 6), nrw = cdiv(W, 10), colv = 60;
-    return (long)N * nrh * nrw * (D / ups) >= 256 && 100L * H * W >= 45L * nrh * nrw * colv;
+    return (long)N * nrh * nrw * (D / ups) >= 128 && 100L * H * W >= 45L * nrh * nrw * colv;
 }
 
 // Path 5: the Winograd kernel whose fp32 products are formed from bf16 triples on the bf16 matrix cores
