@@ -61,7 +61,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ y, int N, int D, int H, int W,
                                                         int Cin, int Cout, int nbd, int nbh, int nbw,
-                                                        float* __restrict__ stat_part) {
+                                                        float* __restrict__ stat_part, int tpr) {
     using C = W2Cfg;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -76,7 +76,9 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     const int by = b % nbh; b /= nbh;
     const int bz = b % nbd;
     const int n = b / nbd;
-    const int z0 = bz * C::BD, y0 = by * C::BH, x0 = bx * C::BW;
+    // tiles per row of a brick plane: 4 (8 x 8 voxels, 16 tiles) or 5 (6 x 10 voxels, 15 tiles: slot 15 empty)
+    const int trows = 16 / tpr;
+    const int z0 = bz * C::BD, y0 = by * 2 * trows, x0 = bx * 2 * tpr;
     const int co0 = blockIdx.y * C::NT;
     const int nchunk = Cin / C::CK;
 
@@ -101,14 +103,14 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     const bool s_on = wave < 6;
     const int s_item = s_on ? wave * 64 + lane : 0;
     const int s_q = s_item & 3, s_r = s_item >> 2;
-    const int s_hz = s_r >> 4, s_th = (s_r >> 2) & 3, s_tw = s_r & 3;
+    const int s_hz = s_r >> 4, s_th = (s_r & 15) / tpr, s_tw = (s_r & 15) - s_th * tpr;
     unsigned pmask = 0;        // validity of the 16 patch voxels
     const int pgz = z0 - 1 + s_hz, pgy = y0 - 1 + 2 * s_th, pgx = x0 - 1 + 2 * s_tw;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const bool ok = s_on && pgz >= 0 && pgz < D && pgy + rr >= 0 && pgy + rr < H && pgx + c >= 0 && pgx + c < W;
+            const bool ok = s_on && s_th < trows && pgz >= 0 && pgz < D && pgy + rr >= 0 && pgy + rr < H && pgx + c >= 0 && pgx + c < W;
             pmask |= (unsigned)ok << (rr * 4 + c);
         }
     // Patch addresses = uniform base (sample, chunk) + a 32-bit per-lane byte offset that is rebuilt from
@@ -263,8 +265,9 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             const float4 zc = *reinterpret_cast<const float4*>(lds + ((((oh + 2) * 2 + wn) * 2 + ow) * 2 + a) * C::EPI_TILE + off);
             float4 v = oh == 0 ? w2add(w2add(za, zb), zc) : w2sub(w2sub(za, zb), zc);
             const int m = a * 32 + row;
-            const int gz = z0 + (m >> 4), gy = y0 + 2 * ((m >> 2) & 3) + oh, gx = x0 + 2 * (m & 3) + ow;
-            if (gz < D && gy < H && gx < W && co < Cout) {
+            const int et = (m & 15) / tpr;
+            const int gz = z0 + (m >> 4), gy = y0 + 2 * et + oh, gx = x0 + 2 * ((m & 15) - et * tpr) + ow;
+            if (et < trows && gz < D && gy < H && gx < W && co < Cout) {
                 s1 = w2add(s1, v);
                 s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
                 s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
@@ -340,7 +343,15 @@ size_t k3_fwd_wino2d_ws_bytes(int Cin, int Cout) {     // one chunk of padding b
     return ((size_t)(Cout / 64) * (Cin / 8) + 1) * 48 * 512 * sizeof(float);
 }
 
-// Same contract as k3_fwd_wino_launch with ups == 1 (stat_part rows: k3_fwd_wino_bricks()).
+// Brick planes of 6 x 10 voxels where they pad the volume less than 8 x 8 ones (10- and 20-wide levels).
+static int w2d_tpr(int H, int W) {
+    return cdiv(H, 6) * 6 * cdiv(W, 10) * 10 * 16 < cdiv(H, 8) * 8 * cdiv(W, 8) * 8 * 15 ? 5 : 4;
+}
+long k3_fwd_wino2d_bricks(int N, int D, int H, int W) {
+    const int tpr = w2d_tpr(H, W);
+    return (long)N * cdiv(D, 4) * cdiv(H, 2 * (16 / tpr)) * cdiv(W, 2 * tpr);
+}
+// Same contract as k3_fwd_wino_launch with ups == 1 (stat_part rows: k3_fwd_wino2d_bricks()).
 int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H,
                          int W, int Cin, int Cout, int flip, void* ws, size_t ws_bytes, hipStream_t s,
                          float* stat_part) {
@@ -351,7 +362,8 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
     if (g > 4096) g = 4096;
     k3_pack_weights_wino2d<<<(unsigned)g, 256, 0, s>>>(w, (float*)ws, Cin, Cout, flip);
     SIV_CHECK_LAUNCH("conv3d_k3(pack 2-D winograd weights)");
-    const int nbd = (D + 3) / 4, nbh = (H + 7) / 8, nbw = (W + 7) / 8;
+    const int tpr = w2d_tpr(H, W);
+    const int nbd = (D + 3) / 4, nbh = (int)cdiv(H, 2 * (16 / tpr)), nbw = (int)cdiv(W, 2 * tpr);
     const long nblk = (long)N * nbd * nbh * nbw;
     if (nblk > 0x7fffffffL) {
         set_error("conv3d_k3(winograd 2-D): too many bricks");
@@ -363,7 +375,7 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
         return SIV_EHIP;
     }
     k3_fwd_wino2d<<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 512, W2Cfg::LDS_BYTES, s>>>(
-        x, (const float*)ws, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part);
+        x, (const float*)ws, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part, tpr);
     SIV_CHECK_LAUNCH("conv3d_k3(winograd 2-D)");
     return SIV_OK;
 }

@@ -53,6 +53,7 @@ size_t k3_fwd_wino_ws_bytes(int Cin, int Cout);
 // conv_wino2d.hip
 bool k3_fwd_wino2d_supported(int Cin, int Cout);
 size_t k3_fwd_wino2d_ws_bytes(int Cin, int Cout);
+long k3_fwd_wino2d_bricks(int N, int D, int H, int W);
 int k3_fwd_wino2d_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int, int,
                          void*, size_t, hipStream_t, float*);
 // conv_wgrad_wino.hip
@@ -116,12 +117,14 @@ static bool use_wino(int path, bool aligned, int N, int D, int H, int W, int Cin
 }
 
 // Two-dimensional Winograd F(2x2,3x3) kernel for the non-upsampled forward / input gradient: on request
-// (path 6) and automatically (path 0) for big volumes (measured 13-18 % faster than the one-dimensional
-// kernel there; slower on the 10x12x10 level, which stays on the direct kernel).
+// (path 6) and automatically (path 0) once the volume gives it enough blocks (measured 13-18 % faster than
+// the one-dimensional kernel on big volumes; the 10- and 20-wide levels run on 6x10-voxel brick planes).
 static bool use_w2d(int path, bool aligned, int ups, int N, int D, int H, int W, int Cin, int Cout) {
     if (ups != 1 || !aligned || !k3_fwd_wino2d_supported(Cin, Cout)) return false;
     if ((long)D * H * W * Cin >= (1L << 29)) return false;      // 32-bit byte offsets inside a sample
-    return path == 6 || (path == 0 && big_volume(N, D, H, W, Cout));
+    // from 160 blocks (bricks of the geometry the kernel picks x 64-channel output tiles): measured 1.4x the
+    // direct kernel at 192 blocks (256->256 @10x12x10, batch 8)
+    return path == 6 || (path == 0 && k3_fwd_wino2d_bricks(N, D, H, W) * (Cout / 64) >= 160);
 }
 
 // Winograd F(3x3,2x2) weight gradient: on request (path 6) and automatically where it was measured
@@ -213,7 +216,7 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
     } else if (use_b3(path, al, ups, Cin, Cout)) {
         fused = B3, wbytes = k3_fwd_wino_b3_ws_bytes(Cin, Cout), nblk = k3_fwd_wino_bricks(N, D, H, W);
     } else if (use_w2d(path, al, ups, N, D, H, W, Cin, Cout)) {
-        fused = W2D, wbytes = k3_fwd_wino2d_ws_bytes(Cin, Cout), nblk = k3_fwd_wino_bricks(N, D, H, W);
+        fused = W2D, wbytes = k3_fwd_wino2d_ws_bytes(Cin, Cout), nblk = k3_fwd_wino2d_bricks(N, D, H, W);
     } else if (use_wino(path, al, N, D, H, W, Cin, Cout)) {
         fused = WINO, wbytes = k3_fwd_wino_ws_bytes(Cin, Cout), nblk = k3_fwd_wino_bricks(N, D, H, W);
     }
