@@ -40,6 +40,10 @@ typedef void* siv_stream_t;  /* hipStream_t */
 
 const char* siv_last_error(void);
 int siv_version(void);
+/* Name of the kernel family the calling thread's last 3x3x3 convolution entry point dispatched to
+ * ("wino2d", "up", "up_wino", "wino", "wino_b3", "mfma", "thin", "generic"): lets tests assert that a
+ * shape really ran on the kernel the automatic path is meant to pick.  No reference counterpart. */
+const char* siv_last_conv_kernel(void);
 /* Upper bound on the scratch any entry point needs for tensors up to the given size. */
 size_t siv_workspace_bytes(void);
 /* Kernel-path override: 0 = automatic (Winograd F(2x2,3x3) forward / input gradient and F(3x3,2x2)
@@ -99,6 +103,22 @@ int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, float* dbias
  * 2x2x2 children of dy.  D,H,W are the extents of dy (even). */
 int siv_upsample2_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C,
                       siv_stream_t stream);
+
+/* ---- 3x3x3 transposed convolution, stride 1, padding 1 ---------------------------------------
+ * Replaces nn.ConvTranspose3d(k=3, s=1, p=1) at models/model.py:202-205 (Decoder_lucky) and its
+ * autograd.  x is [N][D][H][W][Cin], y and dy are [N][D][H][W][Cout]; w is [Cin][kd][kh][kw][Cout]
+ * (channels_last_3d memory of the reference's (Cin,Cout,3,3,3) parameter); bias (Cout) may be NULL.
+ * With stride 1 the operation is the adjoint of siv_conv3d_k3_fwd, so the three calls run on the
+ * same kernels as siv_conv3d_k3_dgrad / _fwd / _wgrad.  accumulate as in siv_conv3d_k3_wgrad. */
+int siv_conv_transpose3d_k3_fwd(const float* x, const float* w, const float* bias, float* y,
+                                int N, int D, int H, int W, int Cin, int Cout,
+                                void* ws, size_t ws_bytes, siv_stream_t stream);
+int siv_conv_transpose3d_k3_dgrad(const float* dy, const float* w, float* dx,
+                                  int N, int D, int H, int W, int Cin, int Cout,
+                                  void* ws, size_t ws_bytes, siv_stream_t stream);
+int siv_conv_transpose3d_k3_wgrad(const float* x, const float* dy, float* dw, float* dbias,
+                                  int N, int D, int H, int W, int Cin, int Cout, int accumulate,
+                                  void* ws, size_t ws_bytes, siv_stream_t stream);
 
 /* ---- 1x1x1 convolution (pointwise linear map over channels) ---------------------
  * Replaces nn.Conv3d(k=1) at models/models.py:35,73 (shortcut projections), :118

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void k3_fwd_generic(const float* __restrict__ 
 // 3x3x3 dgrad: dx[v][ci] = sum_{tap,co} dy[v - (tap-1)][co] * w[co][tap][ci]
 __global__ __launch_bounds__(256) void k3_dgrad_generic(const float* __restrict__ dy,
                                                         const float* __restrict__ w,
+                                                        const float* __restrict__ bias,
                                                         float* __restrict__ dx, int N, int D,
                                                         int H, int W, int Cin, int Cout) {
     const long total = (long)N * D * H * W * Cin;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void k3_dgrad_generic(const float* __restrict_
         const int hh = (int)(v % H); v /= H;
         const int dd = (int)(v % D);
         const int n = (int)(v / D);
-        float acc = 0.f;
+        float acc = bias ? bias[ci] : 0.f;      // bias: the transposed convolution's (per dx channel)
         for (int kd = 0; kd < 3; ++kd) {
             const int zd = dd - kd + 1;
             if (zd < 0 || zd >= D) continue;
@@ -238,9 +239,9 @@ int k3_fwd_generic_launch(const float* x, const float* w, const float* bias, flo
     SIV_CHECK_LAUNCH("conv3d_k3_fwd(generic)");
     return SIV_OK;
 }
-int k3_dgrad_generic_launch(const float* dy, const float* w, float* dx, int N, int D, int H, int W,
-                            int Cin, int Cout, hipStream_t s) {
-    k3_dgrad_generic<<<grid_for((long)N * D * H * W * Cin), 256, 0, s>>>(dy, w, dx, N, D, H, W, Cin,
+int k3_dgrad_generic_launch(const float* dy, const float* w, const float* bias, float* dx, int N, int D,
+                            int H, int W, int Cin, int Cout, hipStream_t s) {
+    k3_dgrad_generic<<<grid_for((long)N * D * H * W * Cin), 256, 0, s>>>(dy, w, bias, dx, N, D, H, W, Cin,
                                                                         Cout);
     SIV_CHECK_LAUNCH("conv3d_k3_dgrad(generic)");
     return SIV_OK;

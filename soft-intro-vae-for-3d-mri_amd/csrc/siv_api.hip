@@ -9,6 +9,9 @@ namespace siv {
 
 static thread_local char g_err[512] = "";
 static std::atomic<int> g_conv_path{0};
+// kernel family the last 3x3x3 convolution entry point of this thread dispatched to (for tests)
+static thread_local const char* g_conv_kernel = "";
+#define SIV_PICK(name) (g_conv_kernel = (name))
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -32,8 +35,8 @@ int conv_path() {
 // conv_generic.hip
 int k3_fwd_generic_launch(const float*, const float*, const float*, float*, int, int, int, int, int,
                           int, int, hipStream_t);
-int k3_dgrad_generic_launch(const float*, const float*, float*, int, int, int, int, int, int,
-                            hipStream_t);
+int k3_dgrad_generic_launch(const float*, const float*, const float*, float*, int, int, int, int, int,
+                            int, hipStream_t);
 int k3_wgrad_generic_launch(const float*, const float*, float*, float*, int, int, int, int, int, int,
                             int, int, void*, size_t, hipStream_t);
 int colsum_launch(const float*, float*, long, int, int, void*, size_t, hipStream_t);
@@ -157,7 +160,8 @@ static bool use_up(int path, bool aligned, int ups, int Cin, int Cout) {
 using namespace siv;
 
 extern "C" const char* siv_last_error(void) { return g_err; }
-extern "C" int siv_version(void) { return 100; }
+extern "C" const char* siv_last_conv_kernel(void) { return g_conv_kernel; }
+extern "C" int siv_version(void) { return 101; }
 extern "C" size_t siv_workspace_bytes(void) { return (size_t)512 << 20; }
 extern "C" int siv_set_conv_path(int path) {
     SIV_CHECK_ARG(path >= 0 && path <= 6, "set_conv_path: path must be 0..6");
@@ -175,20 +179,20 @@ extern "C" int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bi
     const int path = conv_path();
     const bool al = aligned16(x) && aligned16(w) && aligned16(y) && aligned16(ws);
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
-        return k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s);
+        return SIV_PICK("thin"), k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s);
     if (use_up(path, al, ups, Cin, Cout))
-        return k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, nullptr, path == 5, path == 6);
+        return SIV_PICK("up"), k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, nullptr, path == 5, path == 6);
     if (use_b3(path, al, ups, Cin, Cout))
-        return k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, nullptr);
+        return SIV_PICK("wino_b3"), k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, nullptr);
     if (use_w2d(path, al, ups, N, D, H, W, Cin, Cout))
-        return k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, nullptr);
+        return SIV_PICK("wino2d"), k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, nullptr);
     if (use_wino(path, al, N, D, H, W, Cin, Cout))
-        return k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s, nullptr);
+        return SIV_PICK("wino"), k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s, nullptr);
     if (path != 1 && al && k3_fwd_mfma_supported(Cin, Cout))
-        return k3_fwd_mfma_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s);
+        return SIV_PICK("mfma"), k3_fwd_mfma_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s);
     SIV_CHECK_ARG(path != 2, "conv3d_k3_fwd: no specialised kernel for Cin=%d Cout=%d ups=%d", Cin,
                   Cout, ups);
-    return k3_fwd_generic_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, s);
+    return SIV_PICK("generic"), k3_fwd_generic_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, s);
 }
 
 extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const float* bias, float* y,
@@ -224,6 +228,7 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
         wbytes = align256(wbytes);
         SIV_CHECK_WS(wbytes + (size_t)nblk * 2 * Cout * sizeof(float), ws_bytes, "conv3d_k3_fwd_bnstats");
         float* part = (float*)((char*)ws + wbytes);
+        SIV_PICK(fused == UP ? "up" : fused == B3 ? "wino_b3" : fused == W2D ? "wino2d" : "wino");
         switch (fused) {
         case UP: rc = k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, part, path == 5, path == 6); break;
         case B3: rc = k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part); break;
@@ -240,28 +245,68 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
                         ws_bytes, stream);
 }
 
+// Input gradient of the 3x3x3 convolution = forward convolution of dy with the flipped, transposed
+// weights; `bias` (per dx channel, may be NULL) makes the same call a transposed convolution.
+static int dgrad_dispatch(const char* what, const float* dy, const float* w, const float* bias, float* dx,
+                          int N, int D, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes,
+                          hipStream_t s) {
+    const int path = conv_path();
+    const bool al = aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws);
+    if (path != 1 && al && k3_thin_supported(Cout, Cin))
+        return SIV_PICK("thin"), k3_thin_fwd_launch(dy, w, bias, dx, N, D, H, W, Cout, Cin, 1, s);
+    if (use_b3(path, al, 1, Cout, Cin))
+        return SIV_PICK("wino_b3"), k3_fwd_wino_b3_launch(dy, w, bias, dx, N, D, H, W, Cout, Cin, 1, ws, ws_bytes, s, nullptr);
+    if (use_w2d(path, al, 1, N, D, H, W, Cout, Cin))
+        return SIV_PICK("wino2d"), k3_fwd_wino2d_launch(dy, w, bias, dx, N, D, H, W, Cout, Cin, 1, ws, ws_bytes, s, nullptr);
+    if (use_wino(path, al, N, D, H, W, Cout, Cin))
+        return SIV_PICK("wino"), k3_fwd_wino_launch(dy, w, bias, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s, nullptr);
+    if (path != 1 && al && k3_fwd_mfma_supported(Cout, Cin))
+        return SIV_PICK("mfma"), k3_fwd_mfma_launch(dy, w, bias, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s);
+    SIV_CHECK_ARG(path != 2, "%s: no specialised kernel for Cin=%d Cout=%d", what, Cin, Cout);
+    return SIV_PICK("generic"), k3_dgrad_generic_launch(dy, w, bias, dx, N, D, H, W, Cin, Cout, s);
+}
+
 extern "C" int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx, int N, int D, int H,
                                    int W, int Cin, int Cout, void* ws, size_t ws_bytes,
                                    siv_stream_t stream) {
     SIV_CHECK_ARG(dy && w && dx, "conv3d_k3_dgrad: null pointer");
     int rc = check_conv_shape("conv3d_k3_dgrad", N, D, H, W, Cin, Cout, 1);
     if (rc) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    const int path = conv_path();
-    const bool al = aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws);
-    // dgrad is the forward convolution of dy with the flipped, transposed weights
-    if (path != 1 && al && k3_thin_supported(Cout, Cin))
-        return k3_thin_fwd_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, s);
-    if (use_b3(path, al, 1, Cout, Cin))
-        return k3_fwd_wino_b3_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, ws, ws_bytes, s, nullptr);
-    if (use_w2d(path, al, 1, N, D, H, W, Cout, Cin))
-        return k3_fwd_wino2d_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, ws, ws_bytes, s, nullptr);
-    if (use_wino(path, al, N, D, H, W, Cout, Cin))
-        return k3_fwd_wino_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s, nullptr);
-    if (path != 1 && al && k3_fwd_mfma_supported(Cout, Cin))
-        return k3_fwd_mfma_launch(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s);
-    SIV_CHECK_ARG(path != 2, "conv3d_k3_dgrad: no specialised kernel for Cin=%d Cout=%d", Cin, Cout);
-    return k3_dgrad_generic_launch(dy, w, dx, N, D, H, W, Cin, Cout, s);
+    return dgrad_dispatch("conv3d_k3_dgrad", dy, w, nullptr, dx, N, D, H, W, Cin, Cout, ws, ws_bytes,
+                          (hipStream_t)stream);
+}
+
+// ---- nn.ConvTranspose3d(k=3, s=1, p=1): the adjoint of the convolution above ----------------------
+// A transposed convolution Cin -> Cout with weight [Cin][kd][kh][kw][Cout] is the input gradient of the
+// convolution Cout -> Cin that has the same weight array; its own input gradient is that convolution's
+// forward and its weight gradient that convolution's weight gradient with the roles of x and dy swapped.
+extern "C" int siv_conv_transpose3d_k3_fwd(const float* x, const float* w, const float* bias, float* y,
+                                           int N, int D, int H, int W, int Cin, int Cout, void* ws,
+                                           size_t ws_bytes, siv_stream_t stream) {
+    SIV_CHECK_ARG(x && w && y, "conv_transpose3d_k3_fwd: null pointer");
+    int rc = check_conv_shape("conv_transpose3d_k3_fwd", N, D, H, W, Cin, Cout, 1);
+    if (rc) return rc;
+    return dgrad_dispatch("conv_transpose3d_k3_fwd", x, w, bias, y, N, D, H, W, Cout, Cin, ws, ws_bytes,
+                          (hipStream_t)stream);
+}
+
+extern "C" int siv_conv_transpose3d_k3_dgrad(const float* dy, const float* w, float* dx, int N, int D,
+                                             int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes,
+                                             siv_stream_t stream) {
+    SIV_CHECK_ARG(dy && w && dx, "conv_transpose3d_k3_dgrad: null pointer");
+    return siv_conv3d_k3_fwd(dy, w, nullptr, dx, N, D, H, W, Cout, Cin, 1, ws, ws_bytes, stream);
+}
+
+extern "C" int siv_conv_transpose3d_k3_wgrad(const float* x, const float* dy, float* dw, float* dbias,
+                                             int N, int D, int H, int W, int Cin, int Cout,
+                                             int accumulate, void* ws, size_t ws_bytes,
+                                             siv_stream_t stream) {
+    SIV_CHECK_ARG(x && dy && dw, "conv_transpose3d_k3_wgrad: null pointer");
+    int rc = siv_conv3d_k3_wgrad(dy, x, dw, nullptr, N, D, H, W, Cout, Cin, 1, accumulate, ws, ws_bytes, stream);
+    if (rc) return rc;
+    if (dbias)
+        return colsum_launch(dy, dbias, (long)N * D * H * W, Cout, accumulate, ws, ws_bytes, (hipStream_t)stream);
+    return SIV_OK;
 }
 
 extern "C" int siv_conv3d_k3_dgrad_up_supported(int Cin, int Cout) {
@@ -280,6 +325,7 @@ extern "C" int siv_conv3d_k3_dgrad_up(const float* dy, const float* w, float* dx
     SIV_CHECK_ARG(k2_up_dgrad_supported(Cin, Cout),
                   "conv3d_k3_dgrad_up: needs Cin %% 64 == 0 and Cout %% 8 == 0 (got Cin=%d Cout=%d); use "
                   "siv_conv3d_k3_dgrad followed by siv_upsample2_bwd", Cin, Cout);
+    SIV_PICK("up");
     return k2_up_dgrad_launch(dy, w, dx, N, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream, conv_path() == 5,
                               conv_path() == 6);
 }
@@ -294,8 +340,9 @@ extern "C" int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, f
     const int path = conv_path();
     const bool al = aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(ws);
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
-        return k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
+        return SIV_PICK("thin"), k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
     if (use_gw(path, al, ups, N, D, H, W, Cin, Cout)) {
+        SIV_PICK(ups == 2 ? "up_wino" : "wino2d");
         rc = ups == 2 ? k2_up_wgrad_wino_launch(x, dy, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s)
                       : k3_wgrad_wino2d_launch(x, dy, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
         if (rc) return rc;
@@ -303,8 +350,9 @@ extern "C" int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, f
         return SIV_OK;
     }
     if (path != 1 && al && k3_wgrad_mfma_supported(Cin, Cout)) {
+        SIV_PICK("mfma");
         if (ups == 2 && (path == 0 || path == 2 || path >= 5) && k2_up_wgrad_supported(Cin, Cout))
-            rc = k2_up_wgrad_launch(x, dy, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
+            SIV_PICK("up"), rc = k2_up_wgrad_launch(x, dy, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
         else
             rc = k3_wgrad_mfma_launch(x, dy, dw, N, D, H, W, Cin, Cout, ups, accumulate, ws, ws_bytes, s);
         if (rc) return rc;
@@ -313,5 +361,5 @@ extern "C" int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, f
     }
     SIV_CHECK_ARG(path != 2, "conv3d_k3_wgrad: no specialised kernel for Cin=%d Cout=%d ups=%d", Cin,
                   Cout, ups);
-    return k3_wgrad_generic_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, ups, accumulate, ws, ws_bytes, s);
+    return SIV_PICK("generic"), k3_wgrad_generic_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, ups, accumulate, ws, ws_bytes, s);
 }

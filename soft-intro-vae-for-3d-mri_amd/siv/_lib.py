@@ -19,6 +19,9 @@ SIGNATURES = {
     "siv_conv3d_k3_dgrad_up": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_conv3d_k3_dgrad_up_supported": [_i, _i],
     "siv_conv3d_k3_wgrad": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
+    "siv_conv_transpose3d_k3_fwd": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
+    "siv_conv_transpose3d_k3_dgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
+    "siv_conv_transpose3d_k3_wgrad": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_upsample2_bwd": [_f, _f, _i, _i, _i, _i, _i, _f],
     "siv_conv1x1_fwd": [_f, _f, _f, _f, _l, _i, _i, _f],
     "siv_conv1x1_dgrad": [_f, _f, _f, _l, _i, _i, _f],
@@ -72,6 +75,8 @@ def load() -> C.CDLL:
         fn.restype = C.c_int
     lib.siv_last_error.restype = C.c_char_p
     lib.siv_last_error.argtypes = []
+    lib.siv_last_conv_kernel.restype = C.c_char_p
+    lib.siv_last_conv_kernel.argtypes = []
     lib.siv_version.restype = C.c_int
     lib.siv_version.argtypes = []
     lib.siv_workspace_bytes.restype = C.c_size_t

@@ -145,6 +145,48 @@ class HipBackend:
                                                 ws, wsb, self._stream(dy)), "siv_conv3d_k3_wgrad")
         return dw, db
 
+    def last_conv_kernel(self) -> str:
+        """Kernel family the last 3x3x3 convolution call of this thread ran on."""
+        return self.lib.siv_last_conv_kernel().decode()
+
+    # ---- 3x3x3 transposed convolution (nn.ConvTranspose3d k3/s1/p1) ----------------
+    def conv_transpose3d_k3_fwd(self, x, w, bias):
+        """x (N,Cin,D,H,W), w (Cin,Cout,3,3,3) as nn.ConvTranspose3d stores it, bias (Cout) or None."""
+        self._check_dev(x, w, bias)
+        x, w = cl(x), cl(w)
+        N, Cin, D, H, W = x.shape
+        assert w.shape[0] == Cin and tuple(w.shape[2:]) == (3, 3, 3), (tuple(w.shape), Cin)
+        Cout = w.shape[1]
+        y = empty_cl((N, Cout, D, H, W), x)
+        ws, wsb = self._workspace(x)
+        _lib.check(self.lib.siv_conv_transpose3d_k3_fwd(_p(x), _p(w), _p(bias), _p(y), N, D, H, W, Cin, Cout,
+                                                        ws, wsb, self._stream(x)), "siv_conv_transpose3d_k3_fwd")
+        return y
+
+    def conv_transpose3d_k3_dgrad(self, dy, w):
+        self._check_dev(dy, w)
+        dy, w = cl(dy), cl(w)
+        N, Cout, D, H, W = dy.shape
+        Cin = w.shape[0]
+        assert w.shape[1] == Cout, (tuple(w.shape), Cout)
+        dx = empty_cl((N, Cin, D, H, W), dy)
+        ws, wsb = self._workspace(dy)
+        _lib.check(self.lib.siv_conv_transpose3d_k3_dgrad(_p(dy), _p(w), _p(dx), N, D, H, W, Cin, Cout,
+                                                          ws, wsb, self._stream(dy)), "siv_conv_transpose3d_k3_dgrad")
+        return dx
+
+    def conv_transpose3d_k3_wgrad(self, x, dy, want_bias: bool = False):
+        self._check_dev(x, dy)
+        x, dy = cl(x), cl(dy)
+        N, Cout, D, H, W = dy.shape
+        Cin = x.shape[1]
+        dw = empty_cl((Cin, Cout, 3, 3, 3), dy)
+        db = torch.empty(Cout, device=dy.device, dtype=torch.float32) if want_bias else None
+        ws, wsb = self._workspace(dy)
+        _lib.check(self.lib.siv_conv_transpose3d_k3_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, D, H, W, Cin, Cout, 0,
+                                                          ws, wsb, self._stream(dy)), "siv_conv_transpose3d_k3_wgrad")
+        return dw, db
+
     # ---- 1x1x1 convolution -------------------------------------------------------
     def conv1x1_fwd(self, x, w, bias):
         self._check_dev(x, w, bias)

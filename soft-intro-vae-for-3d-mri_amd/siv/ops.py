@@ -75,6 +75,34 @@ def conv3d_k3(x, w, bias=None, ups: int = 1):
     return _Conv3dK3.apply(x, w, bias, ups, None)
 
 
+class _ConvTranspose3dK3(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return get_backend().conv_transpose3d_k3_fwd(x, w, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B = get_backend()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = B.conv_transpose3d_k3_dgrad(dy, w)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            dw, db = B.conv_transpose3d_k3_wgrad(x, dy, want_b)
+            if not ctx.needs_input_grad[1]:
+                dw = None
+        return dx, dw, db
+
+
+def conv_transpose3d_k3(x, w, bias=None):
+    """nn.ConvTranspose3d(kernel_size=3, stride=1, padding=1) (models/model.py:202-205): ``w`` has the
+    module's own (Cin, Cout, 3, 3, 3) shape."""
+    return _ConvTranspose3dK3.apply(x, w, bias)
+
+
 class _Conv1x1(Function):
     @staticmethod
     def forward(ctx, x, w, bias):

@@ -37,6 +37,16 @@ class CpuCheckerBackend:
         dw = nngrad.conv3d_weight(x, (dy.shape[1], x.shape[1], 3, 3, 3), dy, stride=1, padding=1)
         return dw, (dy.sum(dim=(0, 2, 3, 4)) if want_bias else None)
 
+    def conv_transpose3d_k3_fwd(self, x, w, bias):
+        return F.conv_transpose3d(x, w, bias, stride=1, padding=1)
+
+    def conv_transpose3d_k3_dgrad(self, dy, w):
+        return F.conv3d(dy, w, None, 1, 1)
+
+    def conv_transpose3d_k3_wgrad(self, x, dy, want_bias=False):
+        dw = nngrad.conv3d_weight(dy, (x.shape[1], dy.shape[1], 3, 3, 3), x, stride=1, padding=1)
+        return dw, (dy.sum(dim=(0, 2, 3, 4)) if want_bias else None)
+
     def conv1x1_fwd(self, x, w, bias):
         return F.conv3d(x, w, bias)
 

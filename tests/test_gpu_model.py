@@ -16,6 +16,7 @@ import pytest
 import torch
 
 from oracle import siv_oracle as O
+from tests.parity import check_params_after_adam
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -81,7 +82,11 @@ def test_g3_forward_matches_reference_fixture():
         check(a, g[k], k)
 
 
+sd_after = []          # state_dict after each iteration of the last _run_steps call
+
+
 def _run_steps(net, g_inputs, hp, draws, n_steps, lr=2e-4):
+    del sd_after[:]
     import siv.rng as srng
     import siv.utils.my_trainer as trainer
     from siv.optim import FlatAdam
@@ -99,6 +104,7 @@ def _run_steps(net, g_inputs, hp, draws, n_steps, lr=2e-4):
             real, noise = g_inputs(s)
             st = dict(zip(trainer.STAT_NAMES, step(real.cuda(), noise.cuda()).cpu().tolist()))
             out.append((st, dict(grads)))
+            sd_after.append({k: v.detach().clone().cpu() for k, v in net.state_dict().items()})
     return out
 
 
@@ -137,6 +143,18 @@ def test_g4_step_matches_reference_fixture():
             assert int(v) == int(ref_sd[k]), k
         elif k.endswith(("running_mean", "running_var")):
             check(v, ref_sd[k], k, tol=2e-3, floor=2e-4)
+    # weights after the first iteration's two Adam updates (on the device: siv_adam_step over the flat buffers)
+    ref_sd0 = sd_from(g, "s0.sd.")
+    for k, v in sd_after[0].items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(ref_sd0[k]), k
+        elif k.endswith(("running_mean", "running_var")):
+            check(v, ref_sd0[k], k, tol=1e-4, floor=1e-4)
+        elif k.endswith(BN_CANCELLED):
+            np.testing.assert_allclose(v.numpy(), ref_sd0[k].numpy(), rtol=1e-5, atol=2 * 2e-4 + 2e-6, err_msg=k)
+        else:
+            gk = f"s0.{'gradE' if k.startswith('encoder.') else 'gradD'}.{k}"
+            check_params_after_adam(v, ref_sd0[k], g[gk] if gk in g.files else None, 2e-4, k)
 
 
 def test_g6_plain_vae_matches_reference_fixture():
@@ -492,3 +510,94 @@ def test_trainer_fc_runs_on_device(tmp_path):
     assert (tmp_path / "loss.txt").exists() and (tmp_path / "kl_losses.txt").exists()
     sd = torch.load(tmp_path / "prams" / "S-IntroVAE_4184_epoch0.pth", weights_only=True)
     assert list(sd.keys()) == list(net.state_dict().keys())
+
+
+def _fc_init(net, gen):
+    with torch.no_grad():
+        for m in net.modules():
+            if type(m) == torch.nn.Conv3d:
+                torch.nn.init.kaiming_normal_(m.weight, nonlinearity="leaky_relu")
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.copy_(1 + 0.2 * torch.randn(m.weight.shape, generator=gen))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+
+
+class _Draws64(O.Draws):
+    def _emit(self, shape, make):
+        return super()._emit(shape, make).double()
+
+
+def test_fc_wide_step_backward_matches_oracle():
+    """One E+D iteration of the 8-16-32-32 channel FC-latent model (batch 2): losses against the fp32
+    oracle, every gradient "as close to the float64 value of the same formulas as the fp32 oracle is"
+    (tests/fc_truth.py explains why an element-wise fp32 comparison is not meaningful at batch 2)."""
+    import siv.models.mymodel as mymodel
+    from tests.fc_truth import assert_grad_as_good_as_reference
+    torch.manual_seed(31)
+    net = mymodel.SoftIntroVAE(*FC_WIDE)
+    gen = torch.Generator().manual_seed(32)
+    _fc_init(net, gen)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    real = torch.rand(2, 1, 80, 96, 80, generator=gen)
+    noise = torch.randn(2, FC_WIDE[4], generator=gen)
+    cfg, hp = O.FcCfg(*FC_WIDE), O.Hyper()
+    sd32 = {k: v.clone() for k, v in sd.items()}
+    ref = O.soft_intro_step(sd32, cfg, real, noise, O.Draws(seed=33), hp, {}, {})
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    truth = O.soft_intro_step(sd64, cfg, real.double(), noise.double(), _Draws64(seed=33), hp, {}, {})
+    net = net.to("cuda").train()
+    (st, grads), = _run_steps(net, lambda s: (real, noise), hp, O.Draws(seed=33), 1)
+    for mine, r, rt in (("lossE", "lossE", 1e-4), ("kl_real", "kl_real", 1e-4), ("lossD", "lossD", 1e-3),
+                        ("fake_kl", "fake_kl", 1e-3), ("rec_kl", "rec_kl", 1e-3), ("loss_rec", "loss_rec_D", 1e-3)):
+        np.testing.assert_allclose(st[mine], float(ref[r]), rtol=rt, err_msg=mine)
+    for k, gr in grads.items():
+        which = "gradE" if k.startswith("encoder.") else "gradD"
+        rg, tg = ref[which][k], truth[which][k]
+        if rg is None:
+            assert float(gr.abs().max()) == 0.0, k
+        elif float(tg.abs().max()) > 1e-4:                 # skips BN-cancelled convolution biases
+            assert_grad_as_good_as_reference(gr.numpy(), rg.numpy(), tg.numpy(), k)
+
+
+def test_fc_z600_benchmark_model_step():
+    """BASELINE configs[1]: mymodel.SoftIntroVAE(16, 32, 64, 128, 600) at 80x96x80, batch 4 -- training-mode
+    forward against the oracle (1e-4 / 2e-4), then one full E+D iteration: E-step scalars at 1e-4, D-step
+    scalars at 1e-3 (it runs on the encoder after its first, sign-like Adam update), per-parameter gradient
+    norms at 2 % (element-wise comparison: test_fc_wide_step_backward_matches_oracle)."""
+    import siv.models.mymodel as mymodel
+    import siv.rng as srng
+    Z600 = (16, 32, 64, 128, 600)
+    torch.manual_seed(41)
+    net = mymodel.SoftIntroVAE(*Z600)
+    gen = torch.Generator().manual_seed(42)
+    _fc_init(net, gen)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    real = torch.rand(4, 1, 80, 96, 80, generator=gen)
+    noise = torch.randn(4, 600, generator=gen)
+    cfg, hp = O.FcCfg(*Z600), O.Hyper()
+    sdf = {k: v.clone() for k, v in sd.items()}
+    mu_r, lv_r, z_r, x_r = O.forward(real, sdf, cfg, O.Draws(seed=43), True)
+    net = net.to("cuda").train()
+    with srng.use_rng(srng.ReplayRng(O.Draws(seed=43))):
+        mu, lv, z, xr = net.forward(real.cuda())
+    check(mu, mu_r, "mu")
+    check(lv, lv_r, "logvar")
+    check(z, z_r, "z")
+    check(xr, x_r, "x_re", tol=2e-4)
+    net.load_state_dict(sd)                       # undo the running-statistics update of the forward above
+    ref = O.soft_intro_step({k: v.clone() for k, v in sd.items()}, cfg, real, noise, O.Draws(seed=44), hp, {}, {})
+    (st, grads), = _run_steps(net, lambda s: (real, noise), hp, O.Draws(seed=44), 1)
+    for mine, r, rt in (("lossE", "lossE", 1e-4), ("kl_real", "kl_real", 1e-4), ("lossD", "lossD", 1e-3),
+                        ("fake_kl", "fake_kl", 1e-3), ("rec_kl", "rec_kl", 1e-3), ("loss_rec", "loss_rec_D", 1e-3)):
+        np.testing.assert_allclose(st[mine], float(ref[r]), rtol=rt, err_msg=mine)
+    mods = dict(net.named_modules())
+    for k, gr in grads.items():
+        rg = ref["gradE" if k.startswith("encoder.") else "gradD"][k]
+        # every convolution of this model is biased and, except the last one, followed by a BatchNorm that
+        # cancels the gradient of that bias to rounding noise
+        cancelled = (k.endswith(".bias") and isinstance(mods[k.rsplit(".", 1)[0]], torch.nn.Conv3d)
+                     and not k.startswith("decoder.last_block"))
+        if rg is None:
+            assert float(gr.abs().max()) == 0.0, k
+        elif not cancelled:
+            np.testing.assert_allclose(float(gr.norm()), float(rg.norm()), rtol=2e-2, err_msg=k)

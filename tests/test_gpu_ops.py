@@ -473,3 +473,53 @@ def test_conv_fwd_with_bn_statistics(B, cin, cout, dims, n, ups, path, use_bias)
     check(rm, (0.9 * rm0.double() + 0.1 * mr).float(), "running mean")
     check(rv, (0.9 * rv0.double() + 0.1 * vr * m / (m - 1)).float(), "running var")
     assert int(nbt) == 5
+
+
+# nn.ConvTranspose3d(k=3, s=1, p=1): the shapes of models/model.py:202-205 (Decoder_lucky: 8 -> 16 -> 32 -> 64 -> 1
+# on 32 x 24 x 32 volumes ... scaled down in extent for the CPU reference), an odd shape for the generic path and
+# one large enough for the Winograd kernels
+@pytest.mark.parametrize("cin,cout,dims,n,path", [
+    (8, 16, (8, 12, 8), 2, 0), (16, 32, (8, 12, 8), 2, 0), (32, 64, (8, 12, 8), 1, 0), (64, 1, (9, 10, 11), 2, 0),
+    (3, 5, (5, 4, 3), 2, 0), (64, 64, (16, 16, 16), 2, 6), (64, 128, (8, 8, 16), 1, 6), (1, 8, (6, 7, 5), 2, 0),
+])
+def test_conv_transpose3d_k3(B, cin, cout, dims, n, path):
+    gen = torch.Generator().manual_seed(cin * 100 + cout + path)
+    x = rnd(gen, n, cin, *dims)
+    w = rnd(gen, cin, cout, 3, 3, 3, scale=(2.0 / (27 * cin)) ** 0.5)     # nn.ConvTranspose3d's own layout
+    b = rnd(gen, cout)
+    dy = rnd(gen, n, cout, *dims)
+    B.set_conv_path(path)
+    try:
+        y = B.conv_transpose3d_k3_fwd(dev(x), dev(w), dev(b))
+        y_nb = B.conv_transpose3d_k3_fwd(dev(x), dev(w), None)
+        dx = B.conv_transpose3d_k3_dgrad(dev(dy), dev(w))
+        dw, db = B.conv_transpose3d_k3_wgrad(dev(x), dev(dy), True)
+    finally:
+        B.set_conv_path(0)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv_transpose3d(xr, wr, br, stride=1, padding=1)
+    gx, gw, gb = torch.autograd.grad(yr, [xr, wr, br], dy)
+    check(y, yr, "fwd")
+    check(y_nb, F.conv_transpose3d(x, w, None, stride=1, padding=1), "fwd (no bias)")
+    check(dx, gx, "dgrad")
+    check(dw, gw, "wgrad")
+    check(db, gb, "bias grad")
+
+
+def test_conv_transpose3d_autograd(B):
+    """ops.conv_transpose3d_k3 as a differentiable operator, two layers deep with a sigmoid on top as in
+    Decoder_lucky (models/model.py:202-216)."""
+    import siv.ops as ops
+    gen = torch.Generator().manual_seed(21)
+    x = rnd(gen, 2, 8, 6, 8, 6)
+    w1, b1 = rnd(gen, 8, 16, 3, 3, 3, scale=0.1), rnd(gen, 16)
+    w2, b2 = rnd(gen, 16, 1, 3, 3, 3, scale=0.1), rnd(gen, 1)
+    ref_in = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    yr = torch.sigmoid(F.conv_transpose3d(F.conv_transpose3d(ref_in[0], ref_in[1], ref_in[2], 1, 1), ref_in[3], ref_in[4], 1, 1))
+    gr = torch.autograd.grad(yr.square().sum(), ref_in)
+    mine = [dev(t).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    y = torch.sigmoid(ops.conv_transpose3d_k3(ops.conv_transpose3d_k3(mine[0], mine[1], mine[2]), mine[3], mine[4]))
+    gm = torch.autograd.grad(y.square().sum(), mine)
+    check(y, yr, "output")
+    for a, b_, nme in zip(gm, gr, ("dx", "dw1", "db1", "dw2", "db2")):
+        check(a, b_, nme)

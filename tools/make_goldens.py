@@ -576,7 +576,83 @@ def g10_preprocess():
     print("g10_preprocess", {k: (v.dtype, v.shape) for k, v in out.items() if k.startswith("out.")})
 
 
-ALL = {"g10": g10_preprocess, "g7": g7_fc, "g9": g9_train_fc, "g2": g2_blocks, "g3": g3_model, "g4": g4_step, "g5": g5_losses, "g6": g6_vae, "g8": g8_train}
+# ---------------------------------------------------------------- G11 full-size step, fp32 and fp64
+Z1200 = (64, [[64, 1, 2], [128, 1, 2], [256, 2, 2]])       # z-1200main.py:158
+FULL_DIMS = (80, 96, 80)
+
+
+class Draws64(Draws):
+    def _emit(self, shape, make):
+        return super()._emit(shape, make).double()
+
+
+def build_z1200():
+    """The benchmark model as bench.py and tests/test_gpu_fullsize.py construct it: seed 82, He init under
+    seed 77 (z-1200main.py:152, utils/my_trainer.py:160-202), BN gamma/beta moved off (1, 0)."""
+    import models.models as M
+    torch.manual_seed(82)
+    net = M.SoftIntroVAE(*Z1200)
+    torch.manual_seed(77)
+    he_init(net)
+    gen = torch.Generator().manual_seed(103)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, nn.BatchNorm3d):
+                m.weight.copy_(1 + 0.2 * torch.randn(m.weight.shape, generator=gen))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+    return net, gen
+
+
+def g11_fullstep():
+    """One E+D iteration of the REFERENCE z=1200 model at 80x96x80, batch 1, twice: in fp32 (what the
+    reference computes) and with the same modules in float64 (the exact value of the same formulas).  At
+    this size two correct fp32 implementations differ by 1e-3..1e-2 in the end-to-end gradients (BatchNorm
+    cancellation over 614 400 voxels, ~10^8 LeakyReLU kinks, Adam's sign-like first update between the
+    E-step and the D-step), so the fixture records, per scalar and per parameter, how far the reference's
+    own fp32 result is from the float64 one; the GPU test holds libsiv to that distance.  Stored per
+    parameter: max|truth|, max|ref32 - truth|, and 256 sampled elements of both."""
+    _stub_missing_modules()
+    import utils.my_trainer as T
+    hp = dict(scale=8.0 / np.prod(FULL_DIMS), beta_rec=1.0, beta_neg=1024.0, beta_kl=0.75, gamma_r=1e-8)
+    res = {}
+    out = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        net, gen = build_z1200()
+        if tag == "f32":
+            for k, v in net.state_dict().items():
+                out["sd0sum." + k] = np.array(v.double().sum().item())
+        real = torch.rand(1, 1, *FULL_DIMS, generator=gen)
+        noise = torch.randn(1, 1, 10, 12, 10, generator=gen)
+        net = net.to(dt).train()
+        opt_e = torch.optim.Adam(net.encoder.parameters(), lr=2e-4)
+        opt_d = torch.optim.Adam(net.decoder.parameters(), lr=2e-4)
+        draws = (Draws if tag == "f32" else Draws64)(seed=41)
+        with patched_random(draws):
+            res[tag] = reference_step(net, T, real.to(dt), noise.to(dt), opt_e, opt_d, hp)
+        print("g11", tag, "done", flush=True)
+    rs = np.random.RandomState(1234)
+    for k in ("lossE", "kl_real", "lossD", "fake_kl", "rec_kl", "loss_rec_D", "loss_rec_E", "exp_elbo_fake", "exp_elbo_rec"):
+        out["f32." + k], out["f64." + k] = np.array(res["f32"][k]), np.array(res["f64"][k])
+    for which, pre in (("gradE", "encoder."), ("gradD", "decoder.")):
+        for pk, g64 in res["f64"][which].items():
+            key = f"{which}.{pre}{pk}"
+            g32 = res["f32"][which][pk]
+            if g64 is None:
+                out[key + ".none"] = np.array(1)
+                continue
+            g64f, g32f = g64.reshape(-1).numpy(), g32.reshape(-1).numpy().astype(np.float64)
+            idx = np.sort(rs.choice(g64f.size, size=min(g64f.size, 256), replace=False))
+            out[key + ".max"] = np.array(np.abs(g64f).max())
+            out[key + ".err32"] = np.array(np.abs(g32f - g64f).max())
+            out[key + ".idx"], out[key + ".t64"], out[key + ".r32"] = idx, g64f[idx], g32f[idx].astype(np.float32)
+    out["draw_seed"], out["data_seed"] = np.array(41), np.array(103)
+    for k, v in hp.items():
+        out["hp." + k] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, "g11_fullstep.npz"), **out)
+    print("g11_fullstep", len(out), {k: (float(out["f32." + k]), float(out["f64." + k])) for k in ("lossE", "lossD", "fake_kl", "rec_kl")})
+
+
+ALL = {"g11": g11_fullstep, "g10": g10_preprocess, "g7": g7_fc, "g9": g9_train_fc, "g2": g2_blocks, "g3": g3_model, "g4": g4_step, "g5": g5_losses, "g6": g6_vae, "g8": g8_train}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
