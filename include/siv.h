@@ -232,6 +232,15 @@ int siv_kl_bwd(const float* g, const float* mu, const float* logvar, float* dmu,
  * reduction != 'mean', utils/my_trainer.py:62-78 (models/lossf.py:5-12). */
 int siv_sse_fwd(const float* x, const float* y, float* out, int B, long n,
                 void* ws, size_t ws_bytes, siv_stream_t stream);
+/* siv_sse_fwd without a workspace and without any allocation: the per-block partial sums go to a
+ * 512 KiB device array built into the library (one copy per GPU, held until the process ends).
+ * No counterpart in the reference; it is for callers that cannot allocate or carry a workspace:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same result
+ * as siv_sse_fwd bit for bit.  At most 256 samples per call (SIV_EINVAL beyond).  The first call on a
+ * device looks the array's address up (make it outside graph capture); calls that overlap in time on
+ * one GPU share the array and race, so issue them on one stream. */
+int siv_sse_fwd_noalloc(const float* x, const float* y, float* out, int B, long n,
+                        siv_stream_t stream);
 /* dx = 2 g[b] (x-y), dy = -dx; either output may be NULL. */
 int siv_sse_bwd(const float* g, const float* x, const float* y, float* dx, float* dy,
                 int B, long n, siv_stream_t stream);

@@ -1,5 +1,6 @@
 // Latent sampling, per-sample loss reductions, Adam, Philox RNG.  fp32, HBM/latency bound.
 #include "siv_common.h"
+#include <atomic>
 
 namespace siv {
 
@@ -218,6 +219,52 @@ extern "C" int siv_sse_fwd(const float* x, const float* y, float* out, int B, lo
     SIV_CHECK_LAUNCH("sse_fwd(partial)");
     sse_finalize_k<<<(B + 63) / 64, 64, 0, s>>>((const float*)ws, (int)chunks, out, B);
     SIV_CHECK_LAUNCH("sse_fwd(finalize)");
+    return SIV_OK;
+}
+// ---- allocation-free variant of siv_sse_fwd --------------------------------------------------------
+// The per-block partial sums live in a file-scope device array instead of a caller workspace, so the call
+// needs no device memory beyond its inputs and output.  Each GPU the library runs on holds its own copy
+// of the array (SIV_SSE_NOALLOC_MAX_B * 512 floats = 512 KiB) at its own address until the process ends;
+// the address is looked up once per device, with that device current, and the kernels receive it as an
+// ordinary pointer argument.  Every partial a call reads was written by that call, so nothing has to be
+// cleared between calls; two calls that overlap in time on one GPU (different streams) race on the array.
+#define SIV_SSE_NOALLOC_MAX_B 256
+#define SIV_SSE_NOALLOC_MAX_DEVICES 64
+static __device__ __align__(256) float sse_noalloc_scratch[SIV_SSE_NOALLOC_MAX_B * 512];
+static std::atomic<float*> g_sse_noalloc_ptr[SIV_SSE_NOALLOC_MAX_DEVICES];
+
+extern "C" int siv_sse_fwd_noalloc(const float* x, const float* y, float* out, int B, long n,
+                                   siv_stream_t stream) {
+    SIV_CHECK_ARG(x && y && out && B > 0 && n > 0, "sse_fwd_noalloc: bad argument");
+    SIV_CHECK_ARG(B <= SIV_SSE_NOALLOC_MAX_B,
+                  "sse_fwd_noalloc: batch %d exceeds the built-in scratch (at most %d samples per call); use "
+                  "siv_sse_fwd with a workspace", B, SIV_SSE_NOALLOC_MAX_B);
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SIV_SSE_NOALLOC_MAX_DEVICES) {
+        set_error("sse_fwd_noalloc: no current HIP device, or device index %d beyond %d", dev,
+                  SIV_SSE_NOALLOC_MAX_DEVICES - 1);
+        return SIV_EHIP;
+    }
+    float* part = g_sse_noalloc_ptr[dev].load(std::memory_order_acquire);
+    if (!part) {
+        // first call on this device: the array's name is only a host-side handle, its device address
+        // comes from the runtime (a different one on every GPU)
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(sse_noalloc_scratch));
+        if (e != hipSuccess || !p) {
+            set_error("sse_fwd_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return SIV_EHIP;
+        }
+        part = (float*)p;
+        g_sse_noalloc_ptr[dev].store(part, std::memory_order_release);
+    }
+    long chunks = cdiv(n, 256 * 16);
+    if (chunks > 512) chunks = 512;
+    hipStream_t s = (hipStream_t)stream;
+    sse_partial_k<<<dim3((unsigned)chunks, (unsigned)B), 256, 0, s>>>(x, y, part, n);
+    SIV_CHECK_LAUNCH("sse_fwd_noalloc(partial)");
+    sse_finalize_k<<<(B + 63) / 64, 64, 0, s>>>(part, (int)chunks, out, B);
+    SIV_CHECK_LAUNCH("sse_fwd_noalloc(finalize)");
     return SIV_OK;
 }
 extern "C" int siv_sse_bwd(const float* g, const float* x, const float* y, float* dx, float* dy,

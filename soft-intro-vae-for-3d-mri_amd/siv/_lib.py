@@ -45,6 +45,7 @@ SIGNATURES = {
     "siv_kl_fwd": [_f, _f, _f, _i, _l, _f],
     "siv_kl_bwd": [_f, _f, _f, _f, _f, _i, _l, _f],
     "siv_sse_fwd": [_f, _f, _f, _i, _l, _f, _sz, _f],
+    "siv_sse_fwd_noalloc": [_f, _f, _f, _i, _l, _f],
     "siv_sse_bwd": [_f, _f, _f, _f, _f, _i, _l, _f],
     "siv_adam_step": [_f, _f, _f, _f, _l, _fl, _fl, _fl, _fl, _i, _f],
     "siv_randn": [_f, _l, _u64, _u64, _f],
