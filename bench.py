@@ -31,9 +31,34 @@ MODEL = (64, [[64, 1, 2], [128, 1, 2], [256, 2, 2]])     # z-1200main.py:158
 DIMS = (80, 96, 80)
 PER_GPU_BATCH = 8
 FP32_PEAK_TFLOPS = 157.3                                   # MI355X fp32 matrix/vector peak
+HBM_PEAK_TBS = 8.0                                         # MI355X HBM3E peak (about 6.3 TB/s reachable by a copy)
 # dominant kernel: 3x3x3 conv 64->64 at 80x96x80 (60 % of the model's FLOPs):
 # 2 * 27 * 64 * 64 * 614400 = 135.9 GFLOP per volume per launch
 DOM_FLOP_PER_VOLUME = 2.0 * 27 * 64 * 64 * DIMS[0] * DIMS[1] * DIMS[2]
+WINO2D_ISSUED = 12.0 / 27.0        # Winograd F(2x2,3x3) over (H,W): multiply-adds issued per direct one
+WGRAD_ISSUED = 16.0 / 36.0         # Winograd F(3x3,2x2) weight gradient
+UPS_ISSUED = 4.5 / 27.0            # collapsed taps behind a nearest x2 upsample (all three passes)
+
+
+def step_flops_per_volume():
+    """(algorithmic, issued) matrix-core FLOPs of one E+D iteration per volume for the z=1200 model: the
+    wide 3x3x3 convolutions of 5 encoder + 8 decoder forward passes, 5 + 7 input-gradient passes and
+    3 + 4 weight-gradient passes (utils/my_trainer.py:242-325); the single-channel convolutions and the
+    1x1x1 layers (2 % of the FLOPs, HBM bound) are left out of both numbers."""
+    v0 = DIMS[0] * DIMS[1] * DIMS[2]
+    v1, v2, v3 = v0 // 8, v0 // 64, v0 // 512
+    enc = [(64, 64, v0, 1), (64, 64, v1, 1), (64, 128, v1, 1), (128, 128, v2, 1), (128, 256, v2, 1),
+           (256, 256, v3, 1), (256, 256, v3, 1), (256, 256, v3, 1)]
+    dec = [(256, 256, v3, 1), (256, 256, v3, 1), (256, 256, v3, 1), (256, 128, v2, 2), (128, 128, v2, 1),
+           (128, 64, v1, 2), (64, 64, v1, 1), (64, 64, v0, 2)]
+    alg = iss = 0.0
+    for layers, nf, nd, nw in ((enc, 5, 5, 3), (dec, 8, 7, 4)):
+        for cin, cout, vox, ups in layers:
+            f = 2.0 * 27 * cin * cout * vox
+            alg += f * (nf + nd + nw)
+            iss += f * ((nf + nd) * (UPS_ISSUED if ups == 2 else WINO2D_ISSUED)
+                        + nw * (UPS_ISSUED if ups == 2 else WGRAD_ISSUED))
+    return alg, iss
 
 
 def build_model(device):
@@ -46,41 +71,40 @@ def build_model(device):
     return net.to(device).train()
 
 
-def cpu_baseline(budget_s=12.0, max_iters=20):
-    """The CPU oracle (a port: plain torch fp32 on the host cores) on a bounded sample of the same
-    workload: ONE volume through encoder+decoder forward and backward (6 of the 32 network passes of
-    a full step), extrapolated to a full step by the pass count."""
+def cpu_baseline():
+    """The CPU oracle (a port: plain torch fp32 on the host cores) running the SAME iteration -- one full
+    E-step + D-step with both Adam updates of the z=1200 model at 80x96x80 -- at batch 1: one warm-up
+    iteration (oneDNN primitive creation), then the median of three.  Threads: the job's CPU share
+    (OMP_NUM_THREADS when the launcher sets it, else every core)."""
     from oracle import siv_oracle as O
     import siv.models.models as models
     import siv.utils.my_trainer as trainer
-    cores = os.cpu_count() or 1
-    threads = min(cores, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    host_cores = os.cpu_count() or 1
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or host_cores
+    threads = min(threads, host_cores)
     torch.set_num_threads(threads)
     torch.manual_seed(82)
     net = models.SoftIntroVAE(*MODEL)
     torch.manual_seed(77)
     net.apply(trainer.init_weights_he)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    cfg = O.Cfg(*MODEL)
-    x = torch.rand(1, 1, *DIMS, generator=torch.Generator().manual_seed(103))
-    keys = O.param_keys(sd, "encoder.") + O.param_keys(sd, "decoder.")
+    cfg, hp = O.Cfg(*MODEL), O.Hyper(dims=DIMS)
+    gen = torch.Generator().manual_seed(103)
+    ae, ad = {}, {}
     times = []
-    t_start = time.time()
-    for it in range(max_iters):                            # ~budget_s of CPU work, at least 3 repeats
-        for k in keys:
-            sd[k] = sd[k].detach().requires_grad_(True)
+    for it in range(4):
+        x = torch.rand(1, 1, *DIMS, generator=gen)
+        noise = torch.randn(1, 1, DIMS[0] // 8, DIMS[1] // 8, DIMS[2] // 8, generator=gen)
         t0 = time.time()
-        mu, logvar, z, x_re = O.forward(x, sd, cfg, O.Draws(seed=it), True)
-        loss = O.calc_reconstruction_loss(x, x_re, "mean") + O.calc_kl(logvar, mu, "mean")
-        torch.autograd.grad(loss, [sd[k] for k in keys], allow_unused=True)
+        r = O.soft_intro_step(sd, cfg, x, noise, O.Draws(seed=it), hp, ae, ad)
         times.append(time.time() - t0)
-        if it >= 2 and time.time() - t_start > budget_s:
-            break
-    t = min(times)
-    step_s = t * 32.0 / 6.0
-    return {"value": 1.0 / step_s, "unit": "volumes/s", "cores": threads, "kind": "port",
-            "sample": f"1 volume 80x96x80, z=1200 model, encoder+decoder forward+backward (6 of the 32 network "
-                      f"passes of a step) = {t:.2f} s best of {len(times)}, extrapolated x32/6 to a full step"}
+        assert bool(torch.isfinite(r["lossE"])) and bool(torch.isfinite(r["lossD"]))
+    t = sorted(times[1:])[1]
+    return {"value": 1.0 / t, "unit": "volumes/s", "cores": threads, "host_cpu_count": host_cores, "kind": "port",
+            "s_per_step": round(t, 3),
+            "sample": f"the full E-step + D-step (+ 2 Adam updates) of the z=1200 model on ONE 80x96x80 volume "
+                      f"(batch 1), oracle/siv_oracle.py on {threads} threads of {host_cores} host CPUs: 1 warm-up "
+                      f"({times[0]:.1f} s), then median of 3 = {t:.2f} s per step"}
 
 
 def main():
@@ -90,7 +114,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="volumes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-split-bf16", action="store_true", help="skip the second (conv path 5) measurement")
+    ap.add_argument("--split-bf16", action="store_true",
+                    help="also time the opt-in conv path 5 (fp32 products from bf16 triples); never the headline")
     args = ap.parse_args()
 
     # keep stdout for the one JSON line: library banners (RCCL prints its version on the first
@@ -149,6 +174,33 @@ def main():
     B.conv3d_k3_fwd = timed(B.conv3d_k3_fwd)
     B.conv3d_k3_fwd_stats = timed(B.conv3d_k3_fwd_stats)
 
+    # ... and of two HBM-bound members of the step: the BatchNorm+LeakyReLU backward of a 64-channel
+    # full-resolution layer (reads dout and y, writes dy: 3 x 157 MB per volume, + keep mask where there is
+    # one) and the decoder's 64 -> 1 output convolution (reads 157 MB, writes 2.5 MB per volume)
+    hbm_events = {"bn_act_bwd": [], "conv_64_to_1": []}
+
+    def timed_hbm(orig, name, hit_fn, bytes_fn):
+        def call(*a, **k):
+            if not (recording["on"] and hit_fn(*a)):
+                return orig(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(*a, **k)
+            e1.record()
+            hbm_events[name].append((e0, e1, bytes_fn(*a)))
+            return out
+        return call
+
+    B.bn_act_bwd = timed_hbm(
+        B.bn_act_bwd, "bn_act_bwd",
+        # args after (dout, y): mean, var, gamma, beta, res, keep, p, slope, pool, eps, ...
+        lambda dout, y, *r: y.shape[1] == 64 and tuple(y.shape[2:]) == DIMS and r[8] == 1 and r[4] is None,
+        lambda dout, y, *r: 3 * y.numel() * 4 + (y.numel() if r[5] is not None else 0))
+    B.conv3d_k3_fwd = timed_hbm(
+        B.conv3d_k3_fwd, "conv_64_to_1",
+        lambda x, w, *r: w.shape[0] == 1 and w.shape[1] == 64 and tuple(x.shape[2:]) == DIMS,
+        lambda x, w, *r: (x.numel() + x.numel() // 64) * 4)
+
     def one_step(i):
         real = batches[i % n_batches]
         noise = srng.get_rng().eps(net.latent_shape(real.size(0), DIMS), device)
@@ -185,7 +237,7 @@ def main():
     # their fp32 products from bf16 triples on the bf16 matrix cores (conv path 5).  It is NOT the
     # headline value: the headline runs the exact-fp32 matrix-core kernels.
     split = None
-    if not args.no_split_bf16:
+    if args.split_bf16:
         B.set_conv_path(5)
         k2 = max(2, min(args.steps, 5))
         one_step(0)
@@ -213,24 +265,44 @@ def main():
         vols = args.batch * world * args.steps / elapsed
         dom_ms = [e0.elapsed_time(e1) for e0, e1, _ in dom_events]
         roof = None
+        alg_step, iss_step = step_flops_per_volume()
         if dom_ms:
             avg_ms = sum(dom_ms) / len(dom_ms)
-            achieved = DOM_FLOP_PER_VOLUME * args.batch / (avg_ms * 1e-3) / 1e12
+            algorithmic = DOM_FLOP_PER_VOLUME * args.batch / (avg_ms * 1e-3) / 1e12
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
                     traffic = json.load(f).get("hbm_bytes_per_launch")
             # The kernel applies Winograd F(2x2,3x3) over (H, W): it issues 12/27 of the direct-convolution
-            # multiply-adds.  `achieved` is the ALGORITHMIC (direct-convolution) rate and may exceed the
-            # peak; `executed` is the rate of the matrix-core FLOPs actually issued.
-            executed = achieved * 12.0 / 27.0
+            # multiply-adds.  `achieved` / `frac` are the matrix-core FLOPs actually ISSUED against the fp32
+            # MFMA peak (<= 1); `algorithmic_tflops` is the direct-convolution-equivalent rate.
+            achieved = algorithmic * WINO2D_ISSUED
             roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "executed": round(executed, 2), "executed_frac": round(executed / FP32_PEAK_TFLOPS, 4),
+                    "algorithmic_tflops": round(algorithmic, 2),
+                    "algorithmic_bytes_per_launch": int((2 * 64 * 614400 * args.batch + 27 * 64 * 64) * 4),
                     "kernel": "k3_fwd_wino2d (3x3x3 conv 64->64 @80x96x80, Winograd F(2x2,3x3) over (H,W) on fp32 MFMA "
                               "32x32x2: 12 instead of 27 multiply-adds per output and channel pair)",
                     "launches_timed": len(dom_ms), "avg_launch_ms": round(avg_ms, 3)}
+        step_s = elapsed / args.steps
+        roof_step = {"bound": "mfma", "unit": "TFLOP/s", "peak": FP32_PEAK_TFLOPS,
+                     "achieved": round(iss_step * args.batch / step_s / 1e12, 2),
+                     "frac": round(iss_step * args.batch / step_s / 1e12 / FP32_PEAK_TFLOPS, 4),
+                     "algorithmic_tflops": round(alg_step * args.batch / step_s / 1e12, 2),
+                     "what": "whole iteration: matrix-core FLOPs issued by the wide 3x3x3 convolutions of all 13 forward, "
+                             "12 input-gradient and 7 weight-gradient passes / step time (everything else in the step "
+                             "counts as time only)"}
+        roof_hbm = {}
+        for name, evs in hbm_events.items():
+            if evs:
+                ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]
+                byts = sum(b for _, _, b in evs) / len(evs)
+                gbs = byts / (sum(ms) / len(ms) * 1e-3) / 1e9
+                roof_hbm[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
+                                  "frac": round(gbs / (HBM_PEAK_TBS * 1e3), 4), "launches_timed": len(ms),
+                                  "avg_launch_ms": round(sum(ms) / len(ms), 3),
+                                  "algorithmic_bytes_per_launch": int(byts)}
         out = {
             "metric": "MRI volumes/sec (S-IntroVAE step) at 80x96x80 z=1200",
             "value": round(vols, 4), "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
@@ -243,6 +315,8 @@ def main():
                        "rng": "device Philox (dropout, eps, noise)"},
             "host_enqueue_ms_per_step": round(1000.0 * host_elapsed / args.steps, 2),
             "roofline": roof,
+            "roofline_step": roof_step,
+            "roofline_hbm": roof_hbm,
             "split_bf16_products": split,
             "losses": {k: stats[k] for k in ("lossE", "lossD", "loss_rec", "kl_real")},
         }
