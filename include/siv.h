@@ -58,6 +58,25 @@ size_t siv_workspace_bytes(void);
  * weight gradient, product-form / box-form upsampled forward / input gradient) wherever they are supported, whatever the volume. */
 int siv_set_conv_path(int path);
 
+/* ---- packed-weight cache ---------------------------------------------------------------------
+ * The matrix-core convolution kernels read their weights in a packed (and, for the Winograd kernels,
+ * transformed) order that a small kernel produces in front of every convolution launch.  Weights change
+ * only at an optimiser step (utils/my_trainer.py:288,324) while one iteration convolves with them up to
+ * eight times, so a caller may donate device memory in which the packings are kept between calls:
+ *   siv_pack_cache_configure(mem, bytes)  donate `mem` (256-byte aligned; NULL = no cache) on the current device;
+ *   siv_pack_cache_add_weights(lo, bytes) declare [lo, lo+bytes) as weight memory that changes only at
+ *                                         siv_pack_cache_invalidate() calls (weights elsewhere are never cached);
+ *   siv_pack_cache_remove_weights(lo)     the range that starts at lo is no longer weight memory (freed);
+ *   siv_pack_cache_invalidate()           the weights changed: forget every packing;
+ *   siv_pack_cache_hits()                 number of convolution calls served from the cache (diagnostic).
+ * The library allocates nothing; a full cache falls back to packing into the workspace.  Cached packings
+ * are written and read in stream order: use them from one stream.  No reference counterpart. */
+int siv_pack_cache_configure(void* mem, size_t bytes);
+int siv_pack_cache_add_weights(const void* lo, size_t bytes);
+int siv_pack_cache_remove_weights(const void* lo);
+int siv_pack_cache_invalidate(void);
+long siv_pack_cache_hits(void);
+
 /* ---- 3x3x3 convolution, stride 1, zero padding 1 --------------------------------
  * Replaces nn.Conv3d(k=3,s=1,p=1) at models/models.py:17,21,55,59,92,137
  * (models/vaemodel.py:16,20,53,57,88,128).  With ups == 2 the input is first
@@ -244,6 +263,32 @@ int siv_sse_fwd_noalloc(const float* x, const float* y, float* out, int B, long 
 /* dx = 2 g[b] (x-y), dy = -dx; either output may be NULL. */
 int siv_sse_bwd(const float* g, const float* x, const float* y, float* dx, float* dy,
                 int B, long n, siv_stream_t stream);
+
+/* ---- the two objectives of one Soft-IntroVAE iteration --------------------------------------------
+ * The scalar algebra the reference spells with a dozen torch operations per step, from the per-sample
+ * vectors siv_sse_fwd / siv_kl_fwd produce (all of length B, device memory):
+ *  E-step, utils/my_trainer.py:260-284:
+ *    lossE = 10 * ( scale*(beta_rec*mean(sse_real) + beta_kl*mean(kl_real))
+ *                   + 0.5*( mean_b exp(-2 scale (beta_rec*sse_fake + beta_neg*kl_fake))
+ *                         + mean_b exp(-2 scale (beta_rec*sse_rec  + beta_neg*kl_rec )) ) )
+ *    out4 = {lossE, mean(kl_real), exp_elbo_rec, exp_elbo_fake};  _bwd: d6 = [6][B], g[0] times the
+ *    derivative of lossE by sse_real, kl_real, sse_fake, kl_fake, sse_rec, kl_rec.
+ *  D-step, utils/my_trainer.py:301-321:
+ *    lossD = 10 * scale * ( beta_rec*mean(sse_real) + 0.5*beta_kl*(mean(kl_rec) + mean(kl_fake))
+ *                           + gamma_r*0.5*beta_rec*(mean(sse_rec_rec) + mean(sse_fake_rec)) )
+ *    out4 = {lossD, mean(kl_fake), mean(kl_rec), mean(sse_real)};  _bwd: d5 = [5][B] in argument order. */
+int siv_sintro_loss_e_fwd(const float* sse_real, const float* kl_real, const float* sse_fake,
+                          const float* kl_fake, const float* sse_rec, const float* kl_rec, int B,
+                          float scale, float beta_rec, float beta_neg, float beta_kl, float* out4,
+                          siv_stream_t stream);
+int siv_sintro_loss_e_bwd(const float* g, const float* sse_fake, const float* kl_fake,
+                          const float* sse_rec, const float* kl_rec, int B, float scale, float beta_rec,
+                          float beta_neg, float beta_kl, float* d6, siv_stream_t stream);
+int siv_sintro_loss_d_fwd(const float* sse_real, const float* kl_rec, const float* kl_fake,
+                          const float* sse_rec_rec, const float* sse_fake_rec, int B, float scale,
+                          float beta_rec, float beta_kl, float gamma_r, float* out4, siv_stream_t stream);
+int siv_sintro_loss_d_bwd(const float* g, int B, float scale, float beta_rec, float beta_kl, float gamma_r,
+                          float* d5, siv_stream_t stream);
 
 /* ---- optimiser -------------------------------------------------------------------
  * One torch.optim.Adam step (lr, betas, eps; no weight decay, no amsgrad) over a flat

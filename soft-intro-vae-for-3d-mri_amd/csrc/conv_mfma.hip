@@ -343,14 +343,17 @@ int k3_fwd_mfma_launch(const float* x, const float* w, const float* bias, float*
                        int H, int W, int Cin, int Cout, int ups, int flip, void* ws, size_t ws_bytes,
                        hipStream_t s) {
     SIV_CHECK_WS(k3_fwd_mfma_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(mfma)");
-    float* wp = (float*)ws;
     const FwdKind kind = fwd_kind(D, H, W, Cout);
     const int NT = fwd_tile(kind, Cout);
+    bool need_pack;
+    float* wp = (float*)pack_slot(w, PF_MFMA, NT, flip, Cin, Cout, k3_fwd_mfma_ws_bytes(Cin, Cout), ws, &need_pack);
     const long total = (long)((Cout + NT - 1) / NT) * ((Cin + 7) / 8) * 27 * NT * 8;
     long g = cdiv(total, 256);
     if (g > 4096) g = 4096;
-    k3_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout, NT, flip);
-    SIV_CHECK_LAUNCH("conv3d_k3(pack weights)");
+    if (need_pack) {
+        k3_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout, NT, flip);
+        SIV_CHECK_LAUNCH("conv3d_k3(pack weights)");
+    }
 #define SIV_FWD(BD, BH, BW, WM, WN, NTT)                                                              \
     (ups == 1 ? launch_fwd<BD, BH, BW, WM, WN, NTT, 1>(x, wp, bias, y, N, D, H, W, Cin, Cout, s)       \
               : launch_fwd<BD, BH, BW, WM, WN, NTT, 2>(x, wp, bias, y, N, D, H, W, Cin, Cout, s))

@@ -695,29 +695,36 @@ int k2_up_fwd_launch(const float* x, const float* w, const float* bias, float* y
                      int W, int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t s, float* stat_part,
                      bool split, bool force_prod) {
     SIV_CHECK_WS(k2_up_fwd_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(upsampled)");
+    bool need_pack;
     if (up_use_prod(N, D, H, W, split, force_prod)) {
         const long total = (long)(Cout / 64) * 2 * (Cin / 8) * 18 * 512;
         long g = cdiv(total, 256);
         if (g > 4096) g = 4096;
-        k2_up_pack_weights_prod<<<(unsigned)g, 256, 0, s>>>(w, (float*)ws, Cin, Cout);
-        SIV_CHECK_LAUNCH("conv3d_k3(pack upsampled weights, product form)");
-        if (up_wide10(W)) return up_launch_prod<1, 6, 10>(x, ws, bias, y, N, D, H, W, Cin, Cout, s, stat_part);
-        return up_launch_prod<1, 8, 8>(x, ws, bias, y, N, D, H, W, Cin, Cout, s, stat_part);
+        void* wpk = pack_slot(w, PF_UP_PROD, 0, 0, Cin, Cout, k2_up_fwd_ws_bytes(Cin, Cout), ws, &need_pack);
+        if (need_pack) {
+            k2_up_pack_weights_prod<<<(unsigned)g, 256, 0, s>>>(w, (float*)wpk, Cin, Cout);
+            SIV_CHECK_LAUNCH("conv3d_k3(pack upsampled weights, product form)");
+        }
+        if (up_wide10(W)) return up_launch_prod<1, 6, 10>(x, wpk, bias, y, N, D, H, W, Cin, Cout, s, stat_part);
+        return up_launch_prod<1, 8, 8>(x, wpk, bias, y, N, D, H, W, Cin, Cout, s, stat_part);
     }
-    if (split) {
-        const long total = (long)(Cout / 64) * 2 * (Cin / 8) * 32 * 2 * 64 * 2 * 8;
-        long g = cdiv(total, 256);
-        if (g > 4096) g = 4096;
-        k2_up_pack_weights_b3<<<(unsigned)g, 256, 0, s>>>(w, (__bf16*)ws, Cin, Cout);
-    } else {
-        const long total = (long)(Cout / 64) * 2 * (Cin / 8) * 32 * 512;
-        long g = cdiv(total, 256);
-        if (g > 4096) g = 4096;
-        k2_up_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, (float*)ws, Cin, Cout);
+    void* wpk = pack_slot(w, split ? PF_UP_B3 : PF_UP, 0, 0, Cin, Cout, k2_up_fwd_ws_bytes(Cin, Cout), ws, &need_pack);
+    if (need_pack) {
+        if (split) {
+            const long total = (long)(Cout / 64) * 2 * (Cin / 8) * 32 * 2 * 64 * 2 * 8;
+            long g = cdiv(total, 256);
+            if (g > 4096) g = 4096;
+            k2_up_pack_weights_b3<<<(unsigned)g, 256, 0, s>>>(w, (__bf16*)wpk, Cin, Cout);
+        } else {
+            const long total = (long)(Cout / 64) * 2 * (Cin / 8) * 32 * 512;
+            long g = cdiv(total, 256);
+            if (g > 4096) g = 4096;
+            k2_up_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, (float*)wpk, Cin, Cout);
+        }
+        SIV_CHECK_LAUNCH("conv3d_k3(pack upsampled weights)");
     }
-    SIV_CHECK_LAUNCH("conv3d_k3(pack upsampled weights)");
-    if (up_wide10(W)) return up_launch_cfg<1, 12, 10>(x, ws, bias, y, N, D, H, W, Cin, Cout, s, stat_part, split);
-    return up_launch_cfg<2, 8, 8>(x, ws, bias, y, N, D, H, W, Cin, Cout, s, stat_part, split);
+    if (up_wide10(W)) return up_launch_cfg<1, 12, 10>(x, wpk, bias, y, N, D, H, W, Cin, Cout, s, stat_part, split);
+    return up_launch_cfg<2, 8, 8>(x, wpk, bias, y, N, D, H, W, Cin, Cout, s, stat_part, split);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1377,33 +1384,38 @@ int k2_up_dgrad_launch(const float* dy, const float* w, float* dx, int N, int D,
     // tiny volumes keep the 16-tap form
     const bool box = !split && (force_box || (long)N * D * H * W >= (1L << 15));
     SIV_CHECK_WS(k2_up_dgrad_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3_dgrad(upsampled)");
-    if (split) {
-        const long total = (long)(Cin / 64) * (Cout / 8) * 64 * 2 * 64 * 2 * 8;
-        long g = cdiv(total, 256);
-        if (g > 4096) g = 4096;
-        k2_up_pack_dgrad_b3<<<(unsigned)g, 256, 0, s>>>(w, (__bf16*)ws, Cin, Cout);
-    } else if (box) {
-        const long total = (long)(Cin / 64) * (Cout / 8) * 36 * 512;
-        long g = cdiv(total, 256);
-        if (g > 4096) g = 4096;
-        k2_up_pack_dgrad_box<<<(unsigned)g, 256, 0, s>>>(w, (float*)ws, Cin, Cout);
-    } else {
-        const long total = (long)(Cin / 64) * (Cout / 8) * 64 * 512;
-        long g = cdiv(total, 256);
-        if (g > 4096) g = 4096;
-        k2_up_pack_dgrad<<<(unsigned)g, 256, 0, s>>>(w, (float*)ws, Cin, Cout);
+    bool need_pack;
+    void* wpk = pack_slot(w, split ? PF_UPD_B3 : box ? PF_UPD_BOX : PF_UPD, 0, 1, Cin, Cout,
+                          k2_up_dgrad_ws_bytes(Cin, Cout), ws, &need_pack);
+    if (need_pack) {
+        if (split) {
+            const long total = (long)(Cin / 64) * (Cout / 8) * 64 * 2 * 64 * 2 * 8;
+            long g = cdiv(total, 256);
+            if (g > 4096) g = 4096;
+            k2_up_pack_dgrad_b3<<<(unsigned)g, 256, 0, s>>>(w, (__bf16*)wpk, Cin, Cout);
+        } else if (box) {
+            const long total = (long)(Cin / 64) * (Cout / 8) * 36 * 512;
+            long g = cdiv(total, 256);
+            if (g > 4096) g = 4096;
+            k2_up_pack_dgrad_box<<<(unsigned)g, 256, 0, s>>>(w, (float*)wpk, Cin, Cout);
+        } else {
+            const long total = (long)(Cin / 64) * (Cout / 8) * 64 * 512;
+            long g = cdiv(total, 256);
+            if (g > 4096) g = 4096;
+            k2_up_pack_dgrad<<<(unsigned)g, 256, 0, s>>>(w, (float*)wpk, Cin, Cout);
+        }
+        SIV_CHECK_LAUNCH("conv3d_k3_dgrad(pack upsampled weights)");
     }
-    SIV_CHECK_LAUNCH("conv3d_k3_dgrad(pack upsampled weights)");
     if (split) {
-        if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, true>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
-        return up_dgrad_cfg<4, 8, 8, true>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
+        if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, true>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);
+        return up_dgrad_cfg<4, 8, 8, true>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);
     }
     if (box) {
-        if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, false, true>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
-        return up_dgrad_cfg<4, 8, 8, false, true>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
+        if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, false, true>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);
+        return up_dgrad_cfg<4, 8, 8, false, true>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);
     }
-    if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, false>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
-    return up_dgrad_cfg<4, 8, 8, false>(dy, ws, dx, N, D, H, W, Cin, Cout, s);
+    if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, false>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);
+    return up_dgrad_cfg<4, 8, 8, false>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);
 }
 
 }  // namespace siv

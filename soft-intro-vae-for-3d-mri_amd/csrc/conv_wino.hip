@@ -324,12 +324,15 @@ int k3_fwd_wino_launch(const float* x, const float* w, const float* bias, float*
                        int W, int Cin, int Cout, int ups, int flip, void* ws, size_t ws_bytes,
                        hipStream_t s, float* stat_part) {
     SIV_CHECK_WS(k3_fwd_wino_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(winograd)");
-    float* wp = (float*)ws;
+    bool need_pack;
+    float* wp = (float*)pack_slot(w, PF_WINO, 0, flip, Cin, Cout, k3_fwd_wino_ws_bytes(Cin, Cout), ws, &need_pack);
     const long total = (long)((Cout + 63) / 64) * ((Cin + 7) / 8) * 36 * 512;
     long g = cdiv(total, 256);
     if (g > 4096) g = 4096;
-    k3_pack_weights_wino<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout, flip);
-    SIV_CHECK_LAUNCH("conv3d_k3(pack winograd weights)");
+    if (need_pack) {
+        k3_pack_weights_wino<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout, flip);
+        SIV_CHECK_LAUNCH("conv3d_k3(pack winograd weights)");
+    }
     const int nbd = (D + 3) / 4, nbh = (H + 7) / 8, nbw = (W + 7) / 8;
     const long nblk = (long)N * nbd * nbh * nbw;
     if (nblk > 0x7fffffffL) {

@@ -360,8 +360,12 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
     const long total = (long)(Cout / 64) * (Cin / 8) * 48 * 512;
     long g = cdiv(total, 256);
     if (g > 4096) g = 4096;
-    k3_pack_weights_wino2d<<<(unsigned)g, 256, 0, s>>>(w, (float*)ws, Cin, Cout, flip);
-    SIV_CHECK_LAUNCH("conv3d_k3(pack 2-D winograd weights)");
+    bool need_pack;
+    const float* wpk = (const float*)pack_slot(w, PF_WINO2D, 0, flip, Cin, Cout, k3_fwd_wino2d_ws_bytes(Cin, Cout), ws, &need_pack);
+    if (need_pack) {
+        k3_pack_weights_wino2d<<<(unsigned)g, 256, 0, s>>>(w, const_cast<float*>(wpk), Cin, Cout, flip);
+        SIV_CHECK_LAUNCH("conv3d_k3(pack 2-D winograd weights)");
+    }
     const int tpr = w2d_tpr(H, W);
     const int nbd = (D + 3) / 4, nbh = (int)cdiv(H, 2 * (16 / tpr)), nbw = (int)cdiv(W, 2 * tpr);
     const long nblk = (long)N * nbd * nbh * nbw;
@@ -375,7 +379,7 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
         return SIV_EHIP;
     }
     k3_fwd_wino2d<<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 512, W2Cfg::LDS_BYTES, s>>>(
-        x, (const float*)ws, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part, tpr);
+        x, wpk, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part, tpr);
     SIV_CHECK_LAUNCH("conv3d_k3(winograd 2-D)");
     return SIV_OK;
 }

@@ -307,8 +307,12 @@ int k3_fwd_wino_b3_launch(const float* x, const float* w, const float* bias, flo
     const long total = (long)(Cout / 64) * (Cin / 8) * 36 * 2 * 64 * 2 * 8;
     long g = cdiv(total, 256);
     if (g > 4096) g = 4096;
-    k3_pack_weights_wino_b3<<<(unsigned)g, 256, 0, s>>>(w, (__bf16*)ws, Cin, Cout, flip);
-    SIV_CHECK_LAUNCH("conv3d_k3(pack split-bf16 winograd weights)");
+    bool need_pack;
+    void* wpk = pack_slot(w, PF_WINO_B3, 0, flip, Cin, Cout, k3_fwd_wino_b3_ws_bytes(Cin, Cout), ws, &need_pack);
+    if (need_pack) {
+        k3_pack_weights_wino_b3<<<(unsigned)g, 256, 0, s>>>(w, (__bf16*)wpk, Cin, Cout, flip);
+        SIV_CHECK_LAUNCH("conv3d_k3(pack split-bf16 winograd weights)");
+    }
     const int nbd = (D + 3) / 4, nbh = (H + 7) / 8, nbw = (W + 7) / 8;
     const long nblk = (long)N * nbd * nbh * nbw;
     if (nblk > 0x7fffffffL) {
@@ -316,7 +320,7 @@ int k3_fwd_wino_b3_launch(const float* x, const float* w, const float* bias, flo
         return SIV_EINVAL;
     }
     k3_fwd_wino_b3<<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 256, B3Cfg::LDS_BYTES, s>>>(
-        x, (const uint4*)ws, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part);
+        x, (const uint4*)wpk, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part);
     SIV_CHECK_LAUNCH("conv3d_k3(winograd, split bf16)");
     return SIV_OK;
 }

@@ -99,6 +99,87 @@ __global__ __launch_bounds__(256) void sse_bwd_k(const float* __restrict__ g,
     }
 }
 
+// ---- the two scalar objectives of one iteration (one wave each; B is the batch, a handful of samples) ----
+// E-step, utils/my_trainer.py:260-284:
+//   lossE = 10 * ( s*(br*mean(sse_real) + bk*mean(kl_real))
+//                  + 0.5*(mean_b exp(-2s(br*sse_fake + bn*kl_fake)) + mean_b exp(-2s(br*sse_rec + bn*kl_rec))) )
+// out = {lossE, mean(kl_real), exp_elbo_rec, exp_elbo_fake}
+__global__ __launch_bounds__(64) void sintro_loss_e_fwd_k(const float* __restrict__ sse_real, const float* __restrict__ kl_real,
+                                                          const float* __restrict__ sse_fake, const float* __restrict__ kl_fake,
+                                                          const float* __restrict__ sse_rec, const float* __restrict__ kl_rec,
+                                                          int B, float s, float br, float bn, float bk,
+                                                          float* __restrict__ out) {
+    double a = 0.0, k = 0.0, ef = 0.0, er = 0.0;
+    for (int b = threadIdx.x; b < B; b += 64) {
+        a += (double)sse_real[b];
+        k += (double)kl_real[b];
+        ef += (double)expf(-2.f * s * (br * sse_fake[b] + bn * kl_fake[b]));
+        er += (double)expf(-2.f * s * (br * sse_rec[b] + bn * kl_rec[b]));
+    }
+    a = wave_sum_d(a), k = wave_sum_d(k), ef = wave_sum_d(ef), er = wave_sum_d(er);
+    if (threadIdx.x == 0) {
+        const float m_rec = (float)(a / B), m_kl = (float)(k / B), m_ef = (float)(ef / B), m_er = (float)(er / B);
+        out[0] = 10.f * (s * (br * m_rec + bk * m_kl) + 0.5f * (m_ef + m_er));
+        out[1] = m_kl;
+        out[2] = m_er;
+        out[3] = m_ef;
+    }
+}
+// gradients of lossE (times the incoming g) with respect to the six per-sample vectors
+__global__ __launch_bounds__(64) void sintro_loss_e_bwd_k(const float* __restrict__ g, const float* __restrict__ sse_fake,
+                                                          const float* __restrict__ kl_fake, const float* __restrict__ sse_rec,
+                                                          const float* __restrict__ kl_rec, int B, float s, float br,
+                                                          float bn, float bk, float* __restrict__ d /* [6][B] */) {
+    const float g0 = 10.f * g[0];
+    for (int b = threadIdx.x; b < B; b += 64) {
+        const float ef = expf(-2.f * s * (br * sse_fake[b] + bn * kl_fake[b]));
+        const float er = expf(-2.f * s * (br * sse_rec[b] + bn * kl_rec[b]));
+        d[0 * B + b] = g0 * s * br / B;
+        d[1 * B + b] = g0 * s * bk / B;
+        d[2 * B + b] = g0 * 0.5f / B * ef * (-2.f * s * br);
+        d[3 * B + b] = g0 * 0.5f / B * ef * (-2.f * s * bn);
+        d[4 * B + b] = g0 * 0.5f / B * er * (-2.f * s * br);
+        d[5 * B + b] = g0 * 0.5f / B * er * (-2.f * s * bn);
+    }
+}
+// D-step, utils/my_trainer.py:301-321:
+//   lossD = 10 * s * ( br*mean(sse_real) + 0.5*bk*(mean(kl_rec) + mean(kl_fake))
+//                      + gr*0.5*br*(mean(sse_rec_rec) + mean(sse_fake_rec)) )
+// out = {lossD, mean(kl_fake), mean(kl_rec), mean(sse_real)}
+__global__ __launch_bounds__(64) void sintro_loss_d_fwd_k(const float* __restrict__ sse_real, const float* __restrict__ kl_rec,
+                                                          const float* __restrict__ kl_fake, const float* __restrict__ sse_rr,
+                                                          const float* __restrict__ sse_fr, int B, float s, float br,
+                                                          float bk, float gr, float* __restrict__ out) {
+    double a = 0.0, kr = 0.0, kf = 0.0, rr = 0.0, fr = 0.0;
+    for (int b = threadIdx.x; b < B; b += 64) {
+        a += (double)sse_real[b];
+        kr += (double)kl_rec[b];
+        kf += (double)kl_fake[b];
+        rr += (double)sse_rr[b];
+        fr += (double)sse_fr[b];
+    }
+    a = wave_sum_d(a), kr = wave_sum_d(kr), kf = wave_sum_d(kf), rr = wave_sum_d(rr), fr = wave_sum_d(fr);
+    if (threadIdx.x == 0) {
+        const float m_a = (float)(a / B), m_kr = (float)(kr / B), m_kf = (float)(kf / B);
+        const float m_rr = (float)(rr / B), m_fr = (float)(fr / B);
+        out[0] = 10.f * (s * (br * m_a + 0.5f * bk * (m_kr + m_kf) + gr * 0.5f * br * (m_rr + m_fr)));
+        out[1] = m_kf;
+        out[2] = m_kr;
+        out[3] = m_a;
+    }
+}
+__global__ __launch_bounds__(64) void sintro_loss_d_bwd_k(const float* __restrict__ g, int B, float s, float br, float bk,
+                                                          float gr, float* __restrict__ d /* [5][B] */) {
+    const float g0 = 10.f * g[0] * s / B;
+    for (int b = threadIdx.x; b < B; b += 64) {
+        d[0 * B + b] = g0 * br;
+        d[1 * B + b] = g0 * 0.5f * bk;
+        d[2 * B + b] = g0 * 0.5f * bk;
+        d[3 * B + b] = g0 * gr * 0.5f * br;
+        d[4 * B + b] = g0 * gr * 0.5f * br;
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float* __restrict__ g,
                                               float* __restrict__ m, float* __restrict__ v, long n,
                                               float b1, float b2, float eps, float step_size,
@@ -272,6 +353,43 @@ extern "C" int siv_sse_bwd(const float* g, const float* x, const float* y, float
     SIV_CHECK_ARG(g && x && y && (dx || dy) && B > 0 && n > 0, "sse_bwd: bad argument");
     sse_bwd_k<<<ew_grid((long)B * n), 256, 0, (hipStream_t)stream>>>(g, x, y, dx, dy, B, n);
     SIV_CHECK_LAUNCH("sse_bwd");
+    return SIV_OK;
+}
+extern "C" int siv_sintro_loss_e_fwd(const float* sse_real, const float* kl_real, const float* sse_fake,
+                                     const float* kl_fake, const float* sse_rec, const float* kl_rec, int B,
+                                     float scale, float beta_rec, float beta_neg, float beta_kl, float* out4,
+                                     siv_stream_t stream) {
+    SIV_CHECK_ARG(sse_real && kl_real && sse_fake && kl_fake && sse_rec && kl_rec && out4 && B > 0,
+                  "sintro_loss_e_fwd: bad argument");
+    sintro_loss_e_fwd_k<<<1, 64, 0, (hipStream_t)stream>>>(sse_real, kl_real, sse_fake, kl_fake, sse_rec, kl_rec, B,
+                                                           scale, beta_rec, beta_neg, beta_kl, out4);
+    SIV_CHECK_LAUNCH("sintro_loss_e_fwd");
+    return SIV_OK;
+}
+extern "C" int siv_sintro_loss_e_bwd(const float* g, const float* sse_fake, const float* kl_fake,
+                                     const float* sse_rec, const float* kl_rec, int B, float scale, float beta_rec,
+                                     float beta_neg, float beta_kl, float* d6, siv_stream_t stream) {
+    SIV_CHECK_ARG(g && sse_fake && kl_fake && sse_rec && kl_rec && d6 && B > 0, "sintro_loss_e_bwd: bad argument");
+    sintro_loss_e_bwd_k<<<1, 64, 0, (hipStream_t)stream>>>(g, sse_fake, kl_fake, sse_rec, kl_rec, B, scale, beta_rec,
+                                                           beta_neg, beta_kl, d6);
+    SIV_CHECK_LAUNCH("sintro_loss_e_bwd");
+    return SIV_OK;
+}
+extern "C" int siv_sintro_loss_d_fwd(const float* sse_real, const float* kl_rec, const float* kl_fake,
+                                     const float* sse_rec_rec, const float* sse_fake_rec, int B, float scale,
+                                     float beta_rec, float beta_kl, float gamma_r, float* out4, siv_stream_t stream) {
+    SIV_CHECK_ARG(sse_real && kl_rec && kl_fake && sse_rec_rec && sse_fake_rec && out4 && B > 0,
+                  "sintro_loss_d_fwd: bad argument");
+    sintro_loss_d_fwd_k<<<1, 64, 0, (hipStream_t)stream>>>(sse_real, kl_rec, kl_fake, sse_rec_rec, sse_fake_rec, B,
+                                                           scale, beta_rec, beta_kl, gamma_r, out4);
+    SIV_CHECK_LAUNCH("sintro_loss_d_fwd");
+    return SIV_OK;
+}
+extern "C" int siv_sintro_loss_d_bwd(const float* g, int B, float scale, float beta_rec, float beta_kl, float gamma_r,
+                                     float* d5, siv_stream_t stream) {
+    SIV_CHECK_ARG(g && d5 && B > 0, "sintro_loss_d_bwd: bad argument");
+    sintro_loss_d_bwd_k<<<1, 64, 0, (hipStream_t)stream>>>(g, B, scale, beta_rec, beta_kl, gamma_r, d5);
+    SIV_CHECK_LAUNCH("sintro_loss_d_bwd");
     return SIV_OK;
 }
 extern "C" int siv_adam_step(float* p, const float* g, float* m, float* v, long n, float lr,

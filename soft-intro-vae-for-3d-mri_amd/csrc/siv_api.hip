@@ -2,6 +2,10 @@
 // library-wide helpers (error string, version, workspace size, test overrides).
 #include "siv_common.h"
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -30,6 +34,54 @@ int conv_path() {
         return (v >= 0 && v <= 6) ? v : 0;
     }();
     return env_path;
+}
+
+// ---- packed-weight cache --------------------------------------------------------------------------
+// Host-side bookkeeping only: the memory is donated by the caller (siv_pack_cache_configure), one cache
+// per device.  Entries are keyed by (weight pointer, family, variant, flip, Cin, Cout) and live until
+// siv_pack_cache_invalidate.  A slot is filled by the stream of the call that created it; later calls on
+// the same stream read it in order.
+namespace {
+struct PackCache {
+    char* base = nullptr;
+    size_t size = 0, used = 0;
+    std::vector<std::pair<const char*, const char*>> stable;      // [lo, hi) ranges of cacheable weights
+    std::map<std::tuple<const void*, int, int, int, int, int>, size_t> slots;
+    long hits = 0, misses = 0;
+};
+constexpr int kMaxDevices = 64;
+PackCache g_pack[kMaxDevices];
+std::mutex g_pack_mu;
+PackCache* current_cache() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    return &g_pack[dev];
+}
+}  // namespace
+
+void* pack_slot(const void* w, int family, int variant, int flip, int Cin, int Cout, size_t bytes, void* ws,
+                bool* need_pack) {
+    *need_pack = true;
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    PackCache* c = current_cache();
+    if (!c || !c->base) return ws;
+    bool stable = false;
+    for (const auto& r : c->stable) stable = stable || ((const char*)w >= r.first && (const char*)w < r.second);
+    if (!stable) return ws;
+    const auto key = std::make_tuple(w, family, variant, flip, Cin, Cout);
+    auto it = c->slots.find(key);
+    if (it != c->slots.end()) {
+        *need_pack = false;
+        ++c->hits;
+        return c->base + it->second;
+    }
+    const size_t need = align256(bytes);
+    if (c->used + need > c->size) return ws;                      // cache full: pack into the workspace as before
+    const size_t off = c->used;
+    c->used += need;
+    c->slots.emplace(key, off);
+    ++c->misses;
+    return c->base + off;
 }
 
 // conv_generic.hip
@@ -163,6 +215,48 @@ extern "C" const char* siv_last_error(void) { return g_err; }
 extern "C" const char* siv_last_conv_kernel(void) { return g_conv_kernel; }
 extern "C" int siv_version(void) { return 101; }
 extern "C" size_t siv_workspace_bytes(void) { return (size_t)512 << 20; }
+extern "C" int siv_pack_cache_configure(void* mem, size_t bytes) {
+    SIV_CHECK_ARG(((uintptr_t)mem & 255) == 0, "pack_cache_configure: memory must be 256-byte aligned");
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    PackCache* c = current_cache();
+    SIV_CHECK_ARG(c != nullptr, "pack_cache_configure: no current HIP device");
+    *c = PackCache();
+    c->base = (char*)mem;
+    c->size = mem ? bytes : 0;
+    return SIV_OK;
+}
+extern "C" int siv_pack_cache_add_weights(const void* lo, size_t bytes) {
+    SIV_CHECK_ARG(lo && bytes > 0, "pack_cache_add_weights: bad range");
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    PackCache* c = current_cache();
+    SIV_CHECK_ARG(c != nullptr, "pack_cache_add_weights: no current HIP device");
+    c->stable.emplace_back((const char*)lo, (const char*)lo + bytes);
+    c->slots.clear();            // the range may reuse addresses an older range covered
+    c->used = 0;
+    return SIV_OK;
+}
+extern "C" int siv_pack_cache_remove_weights(const void* lo) {
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    PackCache* c = current_cache();
+    if (!c) return SIV_OK;
+    for (size_t i = 0; i < c->stable.size();)
+        if (c->stable[i].first == (const char*)lo) c->stable.erase(c->stable.begin() + i);
+        else ++i;
+    c->slots.clear();
+    c->used = 0;
+    return SIV_OK;
+}
+extern "C" int siv_pack_cache_invalidate(void) {
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    PackCache* c = current_cache();
+    if (c) c->slots.clear(), c->used = 0;
+    return SIV_OK;
+}
+extern "C" long siv_pack_cache_hits(void) {
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    PackCache* c = current_cache();
+    return c ? c->hits : 0;
+}
 extern "C" int siv_set_conv_path(int path) {
     SIV_CHECK_ARG(path >= 0 && path <= 6, "set_conv_path: path must be 0..6");
     g_conv_path.store(path, std::memory_order_relaxed);

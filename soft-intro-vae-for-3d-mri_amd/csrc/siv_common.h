@@ -38,6 +38,14 @@ int conv_path();   // 0 auto, 1 generic, 2 specialised
         }                                                                                \
     } while (0)
 
+// Packed-weight cache (siv_api.hip).  Kernel families that repack their weights ask for the place to
+// pack into: a cached slot when the weight pointer lies inside memory the caller declared stable
+// (siv_pack_cache_add_weights) and the cache has room, otherwise `ws`.  *need_pack is false when the slot
+// already holds this packing (same pointer, family, flip and channel counts since the last invalidation).
+enum PackFamily { PF_MFMA = 1, PF_WINO, PF_WINO_B3, PF_WINO2D, PF_UP_PROD, PF_UP_B3, PF_UP, PF_UPD_B3, PF_UPD_BOX, PF_UPD };
+void* pack_slot(const void* w, int family, int variant, int flip, int Cin, int Cout, size_t bytes, void* ws,
+                bool* need_pack);
+
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 

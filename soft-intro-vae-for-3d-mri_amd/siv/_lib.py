@@ -13,6 +13,10 @@ _i, _l, _fl, _sz, _u64 = C.c_int, C.c_long, C.c_float, C.c_size_t, C.c_uint64
 # name -> argument types; every function returns int (0 = ok)
 SIGNATURES = {
     "siv_set_conv_path": [_i],
+    "siv_pack_cache_configure": [_f, _sz],
+    "siv_pack_cache_add_weights": [_f, _sz],
+    "siv_pack_cache_remove_weights": [_f],
+    "siv_pack_cache_invalidate": [],
     "siv_conv3d_k3_fwd": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_conv3d_k3_fwd_bnstats": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _fl, _f, _sz, _f],
     "siv_conv3d_k3_dgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
@@ -47,6 +51,10 @@ SIGNATURES = {
     "siv_sse_fwd": [_f, _f, _f, _i, _l, _f, _sz, _f],
     "siv_sse_fwd_noalloc": [_f, _f, _f, _i, _l, _f],
     "siv_sse_bwd": [_f, _f, _f, _f, _f, _i, _l, _f],
+    "siv_sintro_loss_e_fwd": [_f, _f, _f, _f, _f, _f, _i, _fl, _fl, _fl, _fl, _f, _f],
+    "siv_sintro_loss_e_bwd": [_f, _f, _f, _f, _f, _i, _fl, _fl, _fl, _fl, _f, _f],
+    "siv_sintro_loss_d_fwd": [_f, _f, _f, _f, _f, _i, _fl, _fl, _fl, _fl, _f, _f],
+    "siv_sintro_loss_d_bwd": [_f, _i, _fl, _fl, _fl, _fl, _f, _f],
     "siv_adam_step": [_f, _f, _f, _f, _l, _fl, _fl, _fl, _fl, _i, _f],
     "siv_randn": [_f, _l, _u64, _u64, _f],
     "siv_dropout_keep": [_f, _l, _fl, _u64, _u64, _f],
@@ -76,6 +84,8 @@ def load() -> C.CDLL:
         fn.restype = C.c_int
     lib.siv_last_error.restype = C.c_char_p
     lib.siv_last_error.argtypes = []
+    lib.siv_pack_cache_hits.restype = C.c_long
+    lib.siv_pack_cache_hits.argtypes = []
     lib.siv_last_conv_kernel.restype = C.c_char_p
     lib.siv_last_conv_kernel.argtypes = []
     lib.siv_version.restype = C.c_int

@@ -43,6 +43,8 @@ class HipBackend:
         self.lib = _lib.load()
         self._ws = {}
         self._side = {}
+        self._pack_cache = {}          # device -> donated cache memory
+        self._stable = {}              # weight pointer -> torch version counter when last used
 
     # ---- plumbing ------------------------------------------------------------
     def _stream(self, t: torch.Tensor) -> int:
@@ -76,12 +78,61 @@ class HipBackend:
             if t is not None and t.dtype not in (torch.float32, torch.uint8, torch.int64):
                 raise _lib.SivError(f"unsupported dtype {t.dtype}")
 
+    # ---- packed-weight cache ---------------------------------------------------
+    PACK_CACHE_BYTES = 768 << 20
+
+    def register_weights(self, flat: torch.Tensor) -> None:
+        """Declare ``flat`` (a flat fp32 parameter buffer) as weight memory that changes only through
+        ``weights_changed()`` or through torch in-place operations (tracked by its version counter): the
+        packed / Winograd-transformed form of convolution weights inside it is then kept between calls."""
+        import weakref
+        self._check_dev(flat)
+        dev = flat.device
+        with torch.cuda.device(dev):
+            if dev not in self._pack_cache:
+                mem = torch.empty(self.PACK_CACHE_BYTES, dtype=torch.uint8, device=dev)
+                self._pack_cache[dev] = mem
+                _lib.check(self.lib.siv_pack_cache_configure(mem.data_ptr(), mem.numel()), "siv_pack_cache_configure")
+            _lib.check(self.lib.siv_pack_cache_add_weights(flat.data_ptr(), flat.numel() * flat.element_size()),
+                       "siv_pack_cache_add_weights")
+        # once the buffer dies its address range may be handed to anything: stop caching inside it
+        weakref.finalize(flat, self._forget_weights, flat.data_ptr(), dev)
+
+    def _forget_weights(self, ptr: int, dev) -> None:
+        try:
+            with torch.cuda.device(dev):
+                self.lib.siv_pack_cache_remove_weights(ptr)
+        except Exception:       # interpreter shutdown
+            pass
+
+    def weights_changed(self, device=None) -> None:
+        """Forget every cached packing (called after an optimiser step wrote the weights behind torch's back)."""
+        if not self._pack_cache:
+            return
+        for dev in ([device] if device is not None else list(self._pack_cache)):
+            if dev in self._pack_cache:
+                with torch.cuda.device(dev):
+                    self.lib.siv_pack_cache_invalidate()
+
+    def _track_weight_version(self, w: torch.Tensor) -> None:
+        # torch-level in-place writes into a cached weight (initialisation, load_state_dict, ...) show in
+        # the tensor's version counter; the optimiser's raw-pointer update reports itself (weights_changed)
+        if not self._pack_cache:
+            return
+        k, v = w.data_ptr(), w._version
+        seen = self._stable.get(k)
+        if seen != v:
+            self._stable[k] = v
+            if seen is not None:
+                self.weights_changed(w.device)
+
     def set_conv_path(self, path: int) -> None:
         _lib.check(self.lib.siv_set_conv_path(path), "siv_set_conv_path")
 
     # ---- 3x3x3 convolution ------------------------------------------------------
     def conv3d_k3_fwd(self, x, w, bias, ups: int = 1):
         self._check_dev(x, w, bias)
+        self._track_weight_version(w)
         x, w = cl(x), cl(w)
         N, Cin, Di, Hi, Wi = x.shape
         Cout = w.shape[0]
@@ -96,6 +147,7 @@ class HipBackend:
     def conv3d_k3_fwd_stats(self, x, w, bias, ups, running_mean, running_var, nbt, momentum: float):
         """Convolution + training-mode BatchNorm statistics of its output: (y, mean, biased var)."""
         self._check_dev(x, w, bias, running_mean, running_var, nbt)
+        self._track_weight_version(w)
         x, w = cl(x), cl(w)
         N, Cin, Di, Hi, Wi = x.shape
         Cout = w.shape[0]
@@ -113,6 +165,7 @@ class HipBackend:
 
     def conv3d_k3_dgrad(self, dy, w, ups: int = 1):
         self._check_dev(dy, w)
+        self._track_weight_version(w)
         dy, w = cl(dy), cl(w)
         N, Cout, D, H, W = dy.shape
         Cin = w.shape[1]
@@ -133,15 +186,27 @@ class HipBackend:
         _lib.check(self.lib.siv_upsample2_bwd(_p(dx), _p(dxs), N, D, H, W, Cin, st), "siv_upsample2_bwd")
         return dxs
 
-    def conv3d_k3_wgrad(self, x, dy, ups: int = 1, want_bias: bool = False):
-        self._check_dev(x, dy)
+    @staticmethod
+    def _grad_targets(shape_w, dy, want_bias, dw_out, db_out, cl_w=True):
+        """Fresh gradient tensors, or the caller's accumulation buffers (``accumulate`` = 1)."""
+        if dw_out is None:
+            dw = empty_cl(shape_w, dy) if cl_w else torch.empty(shape_w, device=dy.device, dtype=torch.float32)
+            db = torch.empty(shape_w[0], device=dy.device, dtype=torch.float32) if want_bias else None
+            return dw, db, 0
+        assert tuple(dw_out.shape) == tuple(shape_w) and dw_out.dtype == torch.float32, (dw_out.shape, shape_w)
+        assert (cl(dw_out) if cl_w else dw_out.contiguous()).data_ptr() == dw_out.data_ptr(), "gradient buffer layout"
+        assert not want_bias or db_out is not None
+        return dw_out, (db_out if want_bias else None), 1
+
+    def conv3d_k3_wgrad(self, x, dy, ups: int = 1, want_bias: bool = False, dw_out=None, db_out=None):
+        """Weight (and bias) gradient; with ``dw_out`` / ``db_out`` the result is ADDED into those buffers."""
+        self._check_dev(x, dy, dw_out, db_out)
         x, dy = cl(x), cl(dy)
         N, Cout, D, H, W = dy.shape
         Cin = x.shape[1]
-        dw = empty_cl((Cout, Cin, 3, 3, 3), dy)
-        db = torch.empty(Cout, device=dy.device, dtype=torch.float32) if want_bias else None
+        dw, db, acc = self._grad_targets((Cout, Cin, 3, 3, 3), dy, want_bias, dw_out, db_out)
         ws, wsb = self._workspace(dy)
-        _lib.check(self.lib.siv_conv3d_k3_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, D, H, W, Cin, Cout, ups, 0,
+        _lib.check(self.lib.siv_conv3d_k3_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, D, H, W, Cin, Cout, ups, acc,
                                                 ws, wsb, self._stream(dy)), "siv_conv3d_k3_wgrad")
         return dw, db
 
@@ -153,6 +218,7 @@ class HipBackend:
     def conv_transpose3d_k3_fwd(self, x, w, bias):
         """x (N,Cin,D,H,W), w (Cin,Cout,3,3,3) as nn.ConvTranspose3d stores it, bias (Cout) or None."""
         self._check_dev(x, w, bias)
+        self._track_weight_version(w)
         x, w = cl(x), cl(w)
         N, Cin, D, H, W = x.shape
         assert w.shape[0] == Cin and tuple(w.shape[2:]) == (3, 3, 3), (tuple(w.shape), Cin)
@@ -165,6 +231,7 @@ class HipBackend:
 
     def conv_transpose3d_k3_dgrad(self, dy, w):
         self._check_dev(dy, w)
+        self._track_weight_version(w)
         dy, w = cl(dy), cl(w)
         N, Cout, D, H, W = dy.shape
         Cin = w.shape[0]
@@ -210,15 +277,14 @@ class HipBackend:
                                               self._stream(dy)), "siv_conv1x1_dgrad")
         return dx
 
-    def conv1x1_wgrad(self, x, dy, want_bias: bool = False):
-        self._check_dev(x, dy)
+    def conv1x1_wgrad(self, x, dy, want_bias: bool = False, dw_out=None, db_out=None):
+        self._check_dev(x, dy, dw_out, db_out)
         x, dy = cl(x), cl(dy)
         N, Cout, D, H, W = dy.shape
         Cin = x.shape[1]
-        dw = torch.empty((Cout, Cin, 1, 1, 1), device=dy.device, dtype=torch.float32)
-        db = torch.empty(Cout, device=dy.device, dtype=torch.float32) if want_bias else None
+        dw, db, acc = self._grad_targets((Cout, Cin, 1, 1, 1), dy, want_bias, dw_out, db_out, cl_w=False)
         ws, wsb = self._workspace(dy)
-        _lib.check(self.lib.siv_conv1x1_wgrad(_p(x), _p(dy), _p(dw), _p(db), N * D * H * W, Cin, Cout, 0,
+        _lib.check(self.lib.siv_conv1x1_wgrad(_p(x), _p(dy), _p(dw), _p(db), N * D * H * W, Cin, Cout, acc,
                                               ws, wsb, self._stream(dy)), "siv_conv1x1_wgrad")
         return dw, db
 
@@ -245,14 +311,13 @@ class HipBackend:
                    "siv_linear_dgrad")
         return dx
 
-    def linear_wgrad(self, x, dy, want_bias: bool = False):
-        self._check_dev(x, dy)
+    def linear_wgrad(self, x, dy, want_bias: bool = False, dw_out=None, db_out=None):
+        self._check_dev(x, dy, dw_out, db_out)
         x, dy = x.contiguous(), dy.contiguous()
         B, K = x.shape
         O = dy.shape[1]
-        dw = torch.empty((O, K), device=dy.device, dtype=torch.float32)
-        db = torch.empty(O, device=dy.device, dtype=torch.float32) if want_bias else None
-        _lib.check(self.lib.siv_linear_wgrad(_p(x), _p(dy), _p(dw), _p(db), B, K, O, 0, self._stream(dy)),
+        dw, db, acc = self._grad_targets((O, K), dy, want_bias, dw_out, db_out, cl_w=False)
+        _lib.check(self.lib.siv_linear_wgrad(_p(x), _p(dy), _p(dw), _p(db), B, K, O, acc, self._stream(dy)),
                    "siv_linear_wgrad")
         return dw, db
 
@@ -344,20 +409,26 @@ class HipBackend:
         return out
 
     def bn_act_bwd(self, dout, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps,
-                   want_affine: bool, want_res: bool):
-        self._check_dev(dout, y, mean, var, gamma, beta, res, keep)
+                   want_affine: bool, want_res: bool, dgamma_out=None, dbeta_out=None):
+        """With ``dgamma_out`` / ``dbeta_out`` the affine gradients are ADDED into those buffers."""
+        self._check_dev(dout, y, mean, var, gamma, beta, res, keep, dgamma_out, dbeta_out)
         dout, y = cl(dout), cl(y)
         res = cl(res) if res is not None else None
         keep = cl(keep) if keep is not None else None
         N, C, D, H, W = y.shape
         dy = like(y)
-        dgamma = torch.empty(C, device=y.device, dtype=torch.float32) if want_affine else None
-        dbeta = torch.empty(C, device=y.device, dtype=torch.float32) if want_affine else None
+        acc = 0
+        if want_affine and dgamma_out is not None:
+            assert dbeta_out is not None and dgamma_out.is_contiguous() and dbeta_out.is_contiguous()
+            dgamma, dbeta, acc = dgamma_out, dbeta_out, 1
+        else:
+            dgamma = torch.empty(C, device=y.device, dtype=torch.float32) if want_affine else None
+            dbeta = torch.empty(C, device=y.device, dtype=torch.float32) if want_affine else None
         dres = like(y) if (want_res and res is not None) else None
         ws, wsb = self._workspace(y)
         _lib.check(self.lib.siv_bn_act_bwd(_p(dout), _p(y), _p(mean), _p(var), _p(gamma), _p(beta), _p(res),
                                            _p(keep), float(p), float(slope), int(pool), float(eps),
-                                           _p(dy), _p(dgamma), _p(dbeta), _p(dres), 0, N, D, H, W, C,
+                                           _p(dy), _p(dgamma), _p(dbeta), _p(dres), acc, N, D, H, W, C,
                                            ws, wsb, self._stream(y)), "siv_bn_act_bwd")
         return dy, dgamma, dbeta, dres
 
@@ -438,6 +509,44 @@ class HipBackend:
         _lib.check(self.lib.siv_sse_bwd(_p(g), _p(x), _p(y), _p(dx), _p(dy), B, x.numel() // B,
                                         self._stream(x)), "siv_sse_bwd")
         return dx, dy
+
+    # ---- the two objectives of one iteration -----------------------------------------
+    def sintro_loss_e_fwd(self, vecs, scale, br, bn, bk):
+        """vecs = (sse_real, kl_real, sse_fake, kl_fake, sse_rec, kl_rec), each (B,) -> tensor
+        [lossE, mean(kl_real), exp_elbo_rec, exp_elbo_fake]."""
+        vecs = [v.contiguous() for v in vecs]
+        self._check_dev(*vecs)
+        B = vecs[0].numel()
+        out = torch.empty(4, device=vecs[0].device, dtype=torch.float32)
+        _lib.check(self.lib.siv_sintro_loss_e_fwd(*[_p(v) for v in vecs], B, float(scale), float(br), float(bn),
+                                                  float(bk), _p(out), self._stream(out)), "siv_sintro_loss_e_fwd")
+        return out
+
+    def sintro_loss_e_bwd(self, g, vecs, scale, br, bn, bk):
+        vecs = [v.contiguous() for v in vecs]
+        B = vecs[0].numel()
+        d = torch.empty((6, B), device=g.device, dtype=torch.float32)
+        _lib.check(self.lib.siv_sintro_loss_e_bwd(_p(g.contiguous()), _p(vecs[2]), _p(vecs[3]), _p(vecs[4]), _p(vecs[5]),
+                                                  B, float(scale), float(br), float(bn), float(bk), _p(d),
+                                                  self._stream(d)), "siv_sintro_loss_e_bwd")
+        return d
+
+    def sintro_loss_d_fwd(self, vecs, scale, br, bk, gr):
+        """vecs = (sse_real, kl_rec, kl_fake, sse_rec_rec, sse_fake_rec) -> tensor
+        [lossD, mean(kl_fake), mean(kl_rec), mean(sse_real)]."""
+        vecs = [v.contiguous() for v in vecs]
+        self._check_dev(*vecs)
+        B = vecs[0].numel()
+        out = torch.empty(4, device=vecs[0].device, dtype=torch.float32)
+        _lib.check(self.lib.siv_sintro_loss_d_fwd(*[_p(v) for v in vecs], B, float(scale), float(br), float(bk),
+                                                  float(gr), _p(out), self._stream(out)), "siv_sintro_loss_d_fwd")
+        return out
+
+    def sintro_loss_d_bwd(self, g, B, scale, br, bk, gr):
+        d = torch.empty((5, B), device=g.device, dtype=torch.float32)
+        _lib.check(self.lib.siv_sintro_loss_d_bwd(_p(g.contiguous()), B, float(scale), float(br), float(bk), float(gr),
+                                                  _p(d), self._stream(d)), "siv_sintro_loss_d_bwd")
+        return d
 
     # ---- optimiser / rng / helpers ---------------------------------------------------
     def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step: int) -> None:

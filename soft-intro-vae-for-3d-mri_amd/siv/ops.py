@@ -17,6 +17,20 @@ BN_MOMENTUM = 0.1
 # (the two are independent, and the deep layers do not fill the chip on their own).  Measured on the
 # z=1200 model: no gain (540 vs 537 ms per iteration), so it is off by default.
 OVERLAP_WGRAD = False
+# Parameters managed by siv.optim.FlatAdam carry ``_siv_grad_buf``, the view of the optimiser's flat
+# gradient buffer that is their ``.grad``.  The backward passes below then ADD each weight / bias /
+# BatchNorm-affine gradient into that view inside the kernel (``accumulate`` = 1 of the C ABI) and hand
+# autograd ``None`` for it: no temporary gradient tensor and no separate accumulation kernel per
+# parameter and pass.  This is the contract of ``loss.backward()`` (gradients end up in ``.grad``);
+# ``torch.autograd.grad`` on such parameters would get ``None`` -- set DIRECT_GRAD = False for that.
+DIRECT_GRAD = True
+
+
+def _grad_buf(p):
+    if not DIRECT_GRAD or p is None:
+        return None
+    buf = getattr(p, "_siv_grad_buf", None)
+    return buf if (buf is not None and p.grad is buf) else None
 
 
 def _wgrad_beside_dgrad(B, dy, wgrad_fn, dgrad_fn):
@@ -42,6 +56,8 @@ class _Conv3dK3(Function):
         ctx.save_for_backward(x, w)
         ctx.ups = ups
         ctx.has_bias = bias is not None
+        ctx.set_materialize_grads(False)       # no zero tensors for the unused (mean, var) outputs
+        ctx.w_buf, ctx.b_buf = _grad_buf(w), _grad_buf(bias)
         if bn is None:
             return get_backend().conv3d_k3_fwd(x, w, bias, ups)
         # training-mode BatchNorm follows: its batch statistics come out of the same call
@@ -56,17 +72,23 @@ class _Conv3dK3(Function):
         x, w = ctx.saved_tensors
         B = get_backend()
         dx = dw = db = None
+        if dy is None:
+            return None, None, None, None, None
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         want_w = ctx.needs_input_grad[1] or want_b
+        direct = ctx.needs_input_grad[1] and ctx.w_buf is not None and (not want_b or ctx.b_buf is not None)
+        wgrad = (lambda: B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b, ctx.w_buf, ctx.b_buf)) if direct else \
+            (lambda: B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b))
         if ctx.needs_input_grad[0] and want_w:
-            dx, (dw, db) = _wgrad_beside_dgrad(B, dy, lambda: B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b),
-                                               lambda: B.conv3d_k3_dgrad(dy, w, ctx.ups))
+            dx, (dw, db) = _wgrad_beside_dgrad(B, dy, wgrad, lambda: B.conv3d_k3_dgrad(dy, w, ctx.ups))
         elif ctx.needs_input_grad[0]:
             dx = B.conv3d_k3_dgrad(dy, w, ctx.ups)
         elif want_w:
-            dw, db = B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b)
-        if not ctx.needs_input_grad[1]:
+            dw, db = wgrad()
+        if direct or not ctx.needs_input_grad[1]:
             dw = None
+        if direct:
+            db = None
         return dx, dw, db, None, None
 
 
@@ -108,6 +130,7 @@ class _Conv1x1(Function):
     def forward(ctx, x, w, bias):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.w_buf, ctx.b_buf = _grad_buf(w), _grad_buf(bias)
         return get_backend().conv1x1_fwd(x, w, bias)
 
     @staticmethod
@@ -119,9 +142,12 @@ class _Conv1x1(Function):
             dx = B.conv1x1_dgrad(dy, w)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_b:
-            dw, db = B.conv1x1_wgrad(x, dy, want_b)
-            if not ctx.needs_input_grad[1]:
-                dw = None
+            if ctx.needs_input_grad[1] and ctx.w_buf is not None and (not want_b or ctx.b_buf is not None):
+                B.conv1x1_wgrad(x, dy, want_b, ctx.w_buf, ctx.b_buf)
+            else:
+                dw, db = B.conv1x1_wgrad(x, dy, want_b)
+                if not ctx.needs_input_grad[1]:
+                    dw = None
         return dx, dw, db
 
 
@@ -135,6 +161,7 @@ class _Linear(Function):
     def forward(ctx, x, w, bias):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.w_buf, ctx.b_buf = _grad_buf(w), _grad_buf(bias)
         return get_backend().linear_fwd(x, w, bias)
 
     @staticmethod
@@ -146,9 +173,12 @@ class _Linear(Function):
             dx = B.linear_dgrad(dy, w)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_b:
-            dw, db = B.linear_wgrad(x, dy, want_b)
-            if not ctx.needs_input_grad[1]:
-                dw = None
+            if ctx.needs_input_grad[1] and ctx.w_buf is not None and (not want_b or ctx.b_buf is not None):
+                B.linear_wgrad(x, dy, want_b, ctx.w_buf, ctx.b_buf)
+            else:
+                dw, db = B.linear_wgrad(x, dy, want_b)
+                if not ctx.needs_input_grad[1]:
+                    dw = None
         return dx, dw, db
 
 
@@ -190,6 +220,7 @@ class _BnAct(Function):
         out = B.bn_act_fwd(y, mean, var, gamma, beta, res, keep, p, slope, pool, bn.eps)
         ctx.save_for_backward(y, mean, var, gamma, beta, res, keep)
         ctx.cfg = (p, slope, pool, bn.eps, train)
+        ctx.g_buf, ctx.b_buf = _grad_buf(gamma), _grad_buf(beta)
         return out
 
     @staticmethod
@@ -201,8 +232,13 @@ class _BnAct(Function):
                                       "training path (the reference validates under torch.no_grad())")
         want_aff = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         want_res = res is not None and ctx.needs_input_grad[3]
-        dy, dg, db, dres = get_backend().bn_act_bwd(dout, y, mean, var, gamma, beta, res, keep, p, slope,
-                                                    pool, eps, want_aff, want_res)
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and ctx.g_buf is not None and ctx.b_buf is not None:
+            dy, _, _, dres = get_backend().bn_act_bwd(dout, y, mean, var, gamma, beta, res, keep, p, slope,
+                                                      pool, eps, True, want_res, ctx.g_buf, ctx.b_buf)
+            dg = db = None
+        else:
+            dy, dg, db, dres = get_backend().bn_act_bwd(dout, y, mean, var, gamma, beta, res, keep, p, slope,
+                                                        pool, eps, want_aff, want_res)
         if not ctx.needs_input_grad[0]:
             dy = None
         return (dy, dg if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None,
@@ -300,3 +336,53 @@ class _SsePerSample(Function):
 def sse_per_sample(x, y):
     """(B,) vector of sum((x - y)^2) per sample."""
     return _SsePerSample.apply(x, y)
+
+
+class _SintroLossE(Function):
+    @staticmethod
+    def forward(ctx, scale, br, bn, bk, *vecs):
+        ctx.save_for_backward(*vecs)
+        ctx.cfg = (scale, br, bn, bk)
+        out = get_backend().sintro_loss_e_fwd(vecs, scale, br, bn, bk)
+        loss, stats = out[0], out[1:]
+        ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, g, g_stats):
+        vecs = ctx.saved_tensors
+        d = get_backend().sintro_loss_e_bwd(g.reshape(1), vecs, *ctx.cfg)
+        return (None, None, None, None) + tuple(d[i] if ctx.needs_input_grad[4 + i] else None for i in range(6))
+
+
+def sintro_loss_e(sse_real, kl_real, sse_fake, kl_fake, sse_rec, kl_rec, scale, beta_rec, beta_neg, beta_kl):
+    """The encoder objective of utils/my_trainer.py:260-284 from six per-sample vectors (one kernel):
+    returns (lossE, stats) with stats = [mean(kl_real), exp_elbo_rec, exp_elbo_fake] (no gradient)."""
+    loss, stats = _SintroLossE.apply(scale, beta_rec, beta_neg, beta_kl, sse_real, kl_real, sse_fake, kl_fake,
+                                     sse_rec, kl_rec)
+    return loss, stats.detach()
+
+
+class _SintroLossD(Function):
+    @staticmethod
+    def forward(ctx, scale, br, bk, gr, *vecs):
+        ctx.cfg = (vecs[0].numel(), scale, br, bk, gr)
+        out = get_backend().sintro_loss_d_fwd(vecs, scale, br, bk, gr)
+        loss, stats = out[0], out[1:]
+        ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, g, g_stats):
+        d = get_backend().sintro_loss_d_bwd(g.reshape(1), *ctx.cfg)
+        return (None, None, None, None) + tuple(d[i] if ctx.needs_input_grad[4 + i] else None for i in range(5))
+
+
+def sintro_loss_d(sse_real, kl_rec, kl_fake, sse_rec_rec, sse_fake_rec, scale, beta_rec, beta_kl, gamma_r):
+    """The decoder objective of utils/my_trainer.py:301-321 from five per-sample vectors (one kernel):
+    returns (lossD, stats) with stats = [mean(kl_fake), mean(kl_rec), mean(sse_real)] (no gradient)."""
+    loss, stats = _SintroLossD.apply(scale, beta_rec, beta_kl, gamma_r, sse_real, kl_rec, kl_fake, sse_rec_rec,
+                                     sse_fake_rec)
+    return loss, stats.detach()

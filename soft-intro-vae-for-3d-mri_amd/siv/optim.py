@@ -63,7 +63,11 @@ class FlatAdam:
                 p.data = view
                 gv = _view_of(self.flat_g, o, p)
                 p.grad = gv
+                p._siv_grad_buf = gv        # siv.ops adds weight gradients straight into this view
                 self._gviews.append(gv)
+        B = get_backend()
+        if dev.type == "cuda" and hasattr(B, "register_weights"):
+            B.register_weights(self.flat_p)       # packed convolution weights are kept between steps
 
     def zero_grad(self) -> None:
         self.flat_g.zero_()
@@ -86,8 +90,11 @@ class FlatAdam:
     def step(self) -> None:
         self._gather_stray_grads()
         self.step_count += 1
-        get_backend().adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr, self.betas[0],
-                                self.betas[1], self.eps, self.step_count)
+        B = get_backend()
+        B.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr, self.betas[0],
+                    self.betas[1], self.eps, self.step_count)
+        if hasattr(B, "weights_changed"):
+            B.weights_changed(self.flat_p.device)
 
 
 class MultiStepLR:

@@ -120,25 +120,20 @@ class SoftIntroStep:
         real_mu, real_logvar = model.encode(real_batch)
         z = model.reparameterize(real_mu, real_logvar)
         rec = model.decode(z)
-        loss_rec = calc_reconstruction_loss(real_batch, rec, reduction="mean")
-        lossE_real_kl = calc_kl(real_logvar, real_mu, reduce="mean")
         rec_mu, rec_logvar, z_rec, rec_rec = model.forward(rec.detach())
         fake_mu, fake_logvar, z_fake, rec_fake = model.forward(fake.detach())
-        fake_kl_e = calc_kl(fake_logvar, fake_mu, reduce="none")
-        rec_kl_e = calc_kl(rec_logvar, rec_mu, reduce="none")
-        loss_fake_rec = calc_reconstruction_loss(fake, rec_fake, reduction="none")
-        loss_rec_rec = calc_reconstruction_loss(rec, rec_rec, reduction="none")      # rec NOT detached (:275)
-        exp_elbo_fake = (-2 * scale * (br * loss_fake_rec + bn * fake_kl_e)).exp().mean()
-        exp_elbo_rec = (-2 * scale * (br * loss_rec_rec + bn * rec_kl_e)).exp().mean()
-        lossE = scale * (br * loss_rec + bk * lossE_real_kl) + 0.5 * (exp_elbo_fake + exp_elbo_rec)
-        lossE = lossE * 10
+        # per-sample terms (:260-275); `rec` is NOT detached in the last one (:275)
+        lossE, se = ops.sintro_loss_e(
+            ops.sse_per_sample(real_batch, rec), ops.kl_per_sample(real_mu, real_logvar),
+            ops.sse_per_sample(fake, rec_fake), ops.kl_per_sample(fake_mu, fake_logvar),
+            ops.sse_per_sample(rec, rec_rec), ops.kl_per_sample(rec_mu, rec_logvar), scale, br, bn, bk)
         self.opt_e.zero_grad()
         lossE.backward()
         self.sync.average_(self.opt_e.flat_g)
         self.opt_e.step()
-        stats_e = (lossE.detach(), lossE_real_kl.detach(), exp_elbo_rec.detach(), exp_elbo_fake.detach())
+        stats_e = (lossE.detach(), se[0], se[1], se[2])      # lossE, kl_real, exp_elbo_rec, exp_elbo_fake
         z = z.detach()
-        del fake, rec, rec_rec, rec_fake, loss_rec, lossE
+        del fake, rec, rec_rec, rec_fake, lossE
 
         # ================ Update D (:291-325) ================
         for p in model.encoder.parameters():
@@ -147,27 +142,23 @@ class SoftIntroStep:
             p.requires_grad = True
         fake = model.decode(noise_batch)
         rec = model.decode(z)
-        loss_rec = calc_reconstruction_loss(real_batch, rec, reduction="mean")
         rec_mu, rec_logvar = model.encode(rec)
         z_rec = model.reparameterize(rec_mu, rec_logvar)
         fake_mu, fake_logvar = model.encode(fake)
         z_fake = model.reparameterize(fake_mu, fake_logvar)
         rec_rec = model.decode(z_rec.detach())
         rec_fake = model.decode(z_fake.detach())
-        loss_rec_rec = calc_reconstruction_loss(rec.detach(), rec_rec, reduction="mean")
-        loss_fake_rec = calc_reconstruction_loss(fake.detach(), rec_fake, reduction="mean")
-        rec_kl = calc_kl(rec_logvar, rec_mu, reduce="mean")
-        fake_kl = calc_kl(fake_logvar, fake_mu, reduce="mean")
-        lossD = scale * (br * loss_rec + 0.5 * bk * (rec_kl + fake_kl)
-                         + gr * 0.5 * br * (loss_rec_rec + loss_fake_rec))
-        lossD = lossD * 10
+        lossD, sd = ops.sintro_loss_d(
+            ops.sse_per_sample(real_batch, rec), ops.kl_per_sample(rec_mu, rec_logvar),
+            ops.kl_per_sample(fake_mu, fake_logvar), ops.sse_per_sample(rec.detach(), rec_rec),
+            ops.sse_per_sample(fake.detach(), rec_fake), scale, br, bk, gr)
         self.opt_d.zero_grad()
         lossD.backward()
         self.sync.average_(self.opt_d.flat_g)
         self.opt_d.step()
+        fake_kl, rec_kl, loss_rec = sd[0], sd[1], sd[2]
         # one device->host copy serves every statistic the trainer logs
-        return torch.stack([stats_e[0], lossD.detach(), stats_e[1], fake_kl.detach(), rec_kl.detach(),
-                            loss_rec.detach(), stats_e[2], stats_e[3]])
+        return torch.stack([stats_e[0], lossD.detach(), stats_e[1], fake_kl, rec_kl, loss_rec, stats_e[2], stats_e[3]])
 
 
 STAT_NAMES = ("lossE", "lossD", "kl_real", "fake_kl", "rec_kl", "loss_rec", "exp_elbo_rec", "exp_elbo_fake")

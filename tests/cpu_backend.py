@@ -31,11 +31,22 @@ class CpuCheckerBackend:
             dx = F.avg_pool3d(dx, ups) * (ups ** 3)
         return dx
 
-    def conv3d_k3_wgrad(self, x, dy, ups=1, want_bias=False):
+    @staticmethod
+    def _into(dw, db, dw_out, db_out):
+        """Mirror of the HIP backend's accumulate-into-buffer mode."""
+        if dw_out is None:
+            return dw, db
+        with torch.no_grad():
+            dw_out += dw
+            if db is not None:
+                db_out += db
+        return dw_out, (db_out if db is not None else None)
+
+    def conv3d_k3_wgrad(self, x, dy, ups=1, want_bias=False, dw_out=None, db_out=None):
         if ups != 1:
             x = F.interpolate(x, scale_factor=ups, mode="nearest")
         dw = nngrad.conv3d_weight(x, (dy.shape[1], x.shape[1], 3, 3, 3), dy, stride=1, padding=1)
-        return dw, (dy.sum(dim=(0, 2, 3, 4)) if want_bias else None)
+        return self._into(dw, (dy.sum(dim=(0, 2, 3, 4)) if want_bias else None), dw_out, db_out)
 
     def conv_transpose3d_k3_fwd(self, x, w, bias):
         return F.conv_transpose3d(x, w, bias, stride=1, padding=1)
@@ -53,9 +64,9 @@ class CpuCheckerBackend:
     def conv1x1_dgrad(self, dy, w):
         return nngrad.conv3d_input((dy.shape[0], w.shape[1]) + tuple(dy.shape[2:]), w, dy)
 
-    def conv1x1_wgrad(self, x, dy, want_bias=False):
+    def conv1x1_wgrad(self, x, dy, want_bias=False, dw_out=None, db_out=None):
         dw = nngrad.conv3d_weight(x, (dy.shape[1], x.shape[1], 1, 1, 1), dy)
-        return dw, (dy.sum(dim=(0, 2, 3, 4)) if want_bias else None)
+        return self._into(dw, (dy.sum(dim=(0, 2, 3, 4)) if want_bias else None), dw_out, db_out)
 
     def linear_fwd(self, x, w, bias):
         return F.linear(x, w, bias)
@@ -63,8 +74,8 @@ class CpuCheckerBackend:
     def linear_dgrad(self, dy, w):
         return dy @ w
 
-    def linear_wgrad(self, x, dy, want_bias=False):
-        return dy.t() @ x, (dy.sum(0) if want_bias else None)
+    def linear_wgrad(self, x, dy, want_bias=False, dw_out=None, db_out=None):
+        return self._into(dy.t() @ x, (dy.sum(0) if want_bias else None), dw_out, db_out)
 
     def add_act_fwd(self, a, b, slope):
         return O.act(a + b, slope)
@@ -100,7 +111,8 @@ class CpuCheckerBackend:
     def bn_act_fwd(self, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps):
         return self._tail(y, mean, var, gamma, beta, res, keep, p, slope, pool, eps)
 
-    def bn_act_bwd(self, dout, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps, want_affine, want_res):
+    def bn_act_bwd(self, dout, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps, want_affine, want_res,
+                   dgamma_out=None, dbeta_out=None):
         # differentiate THROUGH the batch statistics, as training-mode BatchNorm does
         with torch.enable_grad():
             yy = y.detach().requires_grad_(True)
@@ -113,6 +125,11 @@ class CpuCheckerBackend:
             ins = [yy, g, b] + ([r] if r is not None else [])
             grads = torch.autograd.grad(out, ins, dout)
         dres = grads[3] if (r is not None and want_res) else None
+        if want_affine and dgamma_out is not None:
+            with torch.no_grad():
+                dgamma_out += grads[1]
+                dbeta_out += grads[2]
+            return grads[0], dgamma_out, dbeta_out, dres
         return grads[0], (grads[1] if want_affine else None), (grads[2] if want_affine else None), dres
 
     def act_dropout_fwd(self, x, keep, p, slope):
@@ -144,6 +161,30 @@ class CpuCheckerBackend:
     def sse_bwd(self, g, x, y, want_x, want_y):
         d = 2 * g.view(-1, *([1] * (x.dim() - 1))) * (x - y)
         return (d if want_x else None), (-d if want_y else None)
+
+    def sintro_loss_e_fwd(self, vecs, s, br, bn, bk):
+        a, k, sf, kf, sr, kr = vecs
+        ef = (-2 * s * (br * sf + bn * kf)).exp().mean()
+        er = (-2 * s * (br * sr + bn * kr)).exp().mean()
+        return torch.stack([10 * (s * (br * a.mean() + bk * k.mean()) + 0.5 * (ef + er)), k.mean(), er, ef])
+
+    def sintro_loss_e_bwd(self, g, vecs, s, br, bn, bk):
+        with torch.enable_grad():
+            vs = [v.detach().requires_grad_(True) for v in vecs]
+            loss = self.sintro_loss_e_fwd(vs, s, br, bn, bk)[0]
+            gr = torch.autograd.grad(loss, vs, g.reshape(()))
+        return torch.stack(gr)
+
+    def sintro_loss_d_fwd(self, vecs, s, br, bk, gr):
+        a, kr, kf, rr, fr = vecs
+        loss = 10 * (s * (br * a.mean() + 0.5 * bk * (kr.mean() + kf.mean()) + gr * 0.5 * br * (rr.mean() + fr.mean())))
+        return torch.stack([loss, kf.mean(), kr.mean(), a.mean()])
+
+    def sintro_loss_d_bwd(self, g, B, s, br, bk, gr):
+        c = 10 * g.reshape(()) * s / B
+        one = torch.ones(B)
+        return torch.stack([c * br * one, c * 0.5 * bk * one, c * 0.5 * bk * one, c * gr * 0.5 * br * one,
+                            c * gr * 0.5 * br * one])
 
     def adam_step(self, p, g, m, v, lr, beta1, beta2, eps, step):
         st = {0: {"step": step - 1, "m": m, "v": v}}

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"libsiv.so does not export {name}"
     # the ctypes table binds everything that takes device pointers
-    helpers = {"siv_last_error", "siv_version", "siv_workspace_bytes", "siv_last_conv_kernel"}
+    helpers = {"siv_last_error", "siv_version", "siv_workspace_bytes", "siv_last_conv_kernel", "siv_pack_cache_hits"}
     assert set(declared_symbols()) - helpers == set(_lib.SIGNATURES)
     assert lib.siv_version() >= 100
     assert lib.siv_workspace_bytes() >= (64 << 20)

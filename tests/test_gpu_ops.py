@@ -523,3 +523,94 @@ def test_conv_transpose3d_autograd(B):
     check(y, yr, "output")
     for a, b_, nme in zip(gm, gr, ("dx", "dw1", "db1", "dw2", "db2")):
         check(a, b_, nme)
+
+
+@pytest.mark.parametrize("nb", [8, 3, 70])
+def test_sintro_objectives(B, nb):
+    """siv_sintro_loss_e / _d (the scalar algebra of utils/my_trainer.py:260-284 and :301-321) and their
+    gradients against the reference's torch expressions, incl. exp-ELBO terms that underflow."""
+    import siv.ops as ops
+    gen = torch.Generator().manual_seed(nb)
+    s, br, bn, bk, gr = 8.0 / 614400, 1.0, 1024.0, 0.75, 1e-8
+    sse = [torch.rand(nb, generator=gen) * 3e5 for _ in range(5)]
+    kl = [torch.rand(nb, generator=gen) * 40 for _ in range(3)]          # small KLs: exp(-2 s bn kl) ~ e^-1
+    kl[2][0] = 5e4                                                       # ... and one that underflows to 0
+    ve = [sse[0], kl[0], sse[1], kl[1], sse[2], kl[2]]
+    ref_in = [v.clone().requires_grad_(True) for v in ve]
+    a, k, sf, kf, sr, kr = ref_in
+    ef = (-2 * s * (br * sf + bn * kf)).exp().mean()
+    er = (-2 * s * (br * sr + bn * kr)).exp().mean()
+    lossE = 10 * (s * (br * a.mean() + bk * k.mean()) + 0.5 * (ef + er))
+    gref = torch.autograd.grad(lossE, ref_in)
+    mine_in = [dev(v).requires_grad_(True) for v in ve]
+    loss, st = ops.sintro_loss_e(*mine_in, s, br, bn, bk)
+    gm = torch.autograd.grad(loss, mine_in)
+    np.testing.assert_allclose(float(loss), float(lossE), rtol=1e-5)
+    np.testing.assert_allclose(st.cpu().numpy(), [float(k.mean()), float(er), float(ef)], rtol=1e-5)
+    for x, y, n in zip(gm, gref, ("sse_real", "kl_real", "sse_fake", "kl_fake", "sse_rec", "kl_rec")):
+        np.testing.assert_allclose(x.cpu().numpy(), y.numpy(), rtol=1e-5, atol=1e-30, err_msg=n)
+    vd = [sse[0], kl[0], kl[1], sse[3], sse[4]]
+    ref_in = [v.clone().requires_grad_(True) for v in vd]
+    a, kr, kf, rr, fr = ref_in
+    lossD = 10 * (s * (br * a.mean() + 0.5 * bk * (kr.mean() + kf.mean()) + gr * 0.5 * br * (rr.mean() + fr.mean())))
+    gref = torch.autograd.grad(lossD, ref_in)
+    mine_in = [dev(v).requires_grad_(True) for v in vd]
+    loss, st = ops.sintro_loss_d(*mine_in, s, br, bk, gr)
+    gm = torch.autograd.grad(loss, mine_in)
+    np.testing.assert_allclose(float(loss), float(lossD), rtol=1e-5)
+    np.testing.assert_allclose(st.cpu().numpy(), [float(kf.mean()), float(kr.mean()), float(a.mean())], rtol=1e-5)
+    for x, y in zip(gm, gref):
+        np.testing.assert_allclose(x.cpu().numpy(), y.numpy(), rtol=1e-5, atol=1e-30)
+
+
+def test_packed_weight_cache(B):
+    """Weights registered by FlatAdam keep their packed form between calls: the second convolution with the
+    same weights is served from the cache; an optimiser step, and a torch-level in-place write, drop it."""
+    from siv.optim import FlatAdam
+    gen = torch.Generator().manual_seed(31)
+    conv = torch.nn.Conv3d(64, 64, 3, padding=1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(gen, 64, 64, 3, 3, 3, scale=0.05))
+    conv = conv.cuda()
+    opt = FlatAdam(conv.parameters(), lr=0.1)
+    x, dy = rnd(gen, 2, 64, 8, 8, 8), rnd(gen, 2, 64, 8, 8, 8)
+    hits = lambda: B.lib.siv_pack_cache_hits()
+
+    def run():
+        return B.conv3d_k3_fwd(dev(x), conv.weight, None, 1), B.conv3d_k3_dgrad(dev(dy), conv.weight, 1)
+
+    for path in (0, 6):                       # direct matrix-core kernel, two-dimensional Winograd kernel
+        B.set_conv_path(path)
+        try:
+            B.weights_changed()
+            h0 = hits()
+            y1, d1 = run()
+            assert hits() == h0                                   # first use packs
+            y2, d2 = run()
+            assert hits() == h0 + 2 and torch.equal(y1, y2) and torch.equal(d1, d2)
+            w_cpu = conv.weight.detach().cpu()
+            check(y2, O.conv3d_k3(x, w_cpu, None, 1), "fwd from cache")
+            # an optimiser step changes the weights behind torch's back and must drop the packings
+            opt.zero_grad()
+            conv.weight.grad.copy_(torch.sign(rnd(gen, 64, 64, 3, 3, 3)).cuda())
+            opt.step()
+            h1 = hits()
+            y3, d3 = run()
+            assert hits() == h1
+            w_cpu = conv.weight.detach().cpu()
+            assert float((w_cpu - y1.new_zeros(1).cpu()).abs().max()) > 0
+            check(y3, O.conv3d_k3(x, w_cpu, None, 1), "fwd after step")
+            assert not torch.equal(y3, y2)
+            # a torch in-place write is seen through the tensor's version counter
+            with torch.no_grad():
+                conv.weight.mul_(2.0)
+            y4, _ = run()
+            check(y4, O.conv3d_k3(x, 2 * w_cpu, None, 1), "fwd after in-place write")
+            # weights outside any registered buffer are never cached
+            h2 = hits()
+            w_loose = dev(rnd(gen, 64, 64, 3, 3, 3, scale=0.05))
+            B.conv3d_k3_fwd(dev(x), w_loose, None, 1)
+            B.conv3d_k3_fwd(dev(x), w_loose, None, 1)
+            assert hits() == h2
+        finally:
+            B.set_conv_path(0)
