@@ -139,9 +139,10 @@ def main():
     assert B.name == "hip"
 
     net = build_model(device)
+    sync = GradSync(device)
+    sync.broadcast_(net)                                   # replicas start from rank 0's parameters and buffers
     opt_e = FlatAdam(net.encoder.parameters(), lr=2e-4)
     opt_d = FlatAdam(net.decoder.parameters(), lr=2e-4)
-    sync = GradSync(device)
     step = trainer.SoftIntroStep(net, opt_e, opt_d, 1.0, 1024.0, 0.75, 1e-8, None, sync)
     srng.manual_seed(77, rank)
 

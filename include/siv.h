@@ -307,8 +307,12 @@ int siv_dropout_keep(uint8_t* keep, long n, float p, uint64_t seed, uint64_t str
                      siv_stream_t stream);
 
 /* ---- helpers ------------------------------------------------------------------------ */
-/* y = a*x + b*y elementwise (gradient accumulation / scaling on device). */
+/* y = a*x + b*y elementwise (gradient accumulation on device); x and y must not overlap. */
 int siv_axpby(float a, const float* x, float b, float* y, long n, siv_stream_t stream);
+/* x *= a in place: the division by the world size after the gradient all-reduce that replaces
+ * nn.DataParallel's reduce_add (main_DataParallel.py:609).  The collective itself is not part of this
+ * library: callers run it with torch.distributed (backend "nccl" = RCCL over xGMI) on the same stream. */
+int siv_scale(float a, float* x, long n, siv_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -196,6 +196,11 @@ __global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float
     }
 }
 
+__global__ __launch_bounds__(256) void scale_k(float a, float* x, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        x[i] *= a;
+}
+// x and y must not overlap (siv_scale is the in-place form)
 __global__ __launch_bounds__(256) void axpby_k(float a, const float* __restrict__ x, float b,
                                                float* __restrict__ y, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -416,8 +421,15 @@ extern "C" int siv_dropout_keep(uint8_t* keep, long n, float p, uint64_t seed, u
     SIV_CHECK_LAUNCH("dropout_keep");
     return SIV_OK;
 }
+extern "C" int siv_scale(float a, float* x, long n, siv_stream_t stream) {
+    SIV_CHECK_ARG(x && n > 0, "scale: bad argument");
+    scale_k<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(a, x, n);
+    SIV_CHECK_LAUNCH("scale");
+    return SIV_OK;
+}
 extern "C" int siv_axpby(float a, const float* x, float b, float* y, long n, siv_stream_t stream) {
     SIV_CHECK_ARG(x && y && n > 0, "axpby: bad argument");
+    SIV_CHECK_ARG(x + n <= y || y + n <= x, "axpby: x and y must not overlap (use siv_scale to scale in place)");
     axpby_k<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(a, x, b, y, n);
     SIV_CHECK_LAUNCH("axpby");
     return SIV_OK;

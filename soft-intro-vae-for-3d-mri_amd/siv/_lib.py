@@ -59,6 +59,7 @@ SIGNATURES = {
     "siv_randn": [_f, _l, _u64, _u64, _f],
     "siv_dropout_keep": [_f, _l, _fl, _u64, _u64, _f],
     "siv_axpby": [_fl, _f, _fl, _f, _l, _f],
+    "siv_scale": [_fl, _f, _l, _f],
 }
 
 _lib = None

@@ -572,6 +572,12 @@ class HipBackend:
                    "siv_dropout_keep")
         return out
 
+    def scale_(self, x, a: float) -> None:
+        """x *= a in place."""
+        self._check_dev(x)
+        assert x.is_contiguous()
+        _lib.check(self.lib.siv_scale(float(a), _p(x), x.numel(), self._stream(x)), "siv_scale")
+
     def axpby(self, a: float, x, b: float, y) -> None:
         self._check_dev(x, y)
         assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()

@@ -49,7 +49,8 @@ def init_process_group(backend: str = None):
 
 
 class GradSync:
-    """Averages a flat gradient buffer over all ranks."""
+    """Keeps the replicas of a data-parallel job in step: initial broadcast of parameters and buffers,
+    averaging of a flat gradient buffer over all ranks, and the optimiser step that follows it."""
 
     def __init__(self, device=None):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -58,6 +59,7 @@ class GradSync:
         self.collective = self.world > 1 or (_forced() and dist.is_initialized())
         if self.collective and device is not None and torch.device(device).type == "cuda":
             self.side = torch.cuda.Stream(device=device)
+        self._pending = None           # event recorded on the side stream behind an exchange + step
 
     def shard(self, batch: torch.Tensor) -> torch.Tensor:
         """Rank r's slice [r*B/W, (r+1)*B/W) of a global batch."""
@@ -69,15 +71,67 @@ class GradSync:
         per = b // self.world
         return batch[self.rank * per:(self.rank + 1) * per]
 
+    def broadcast_(self, module: torch.nn.Module, src: int = 0) -> None:
+        """Every rank takes rank ``src``'s parameters and buffers (what nn.DataParallel's per-forward
+        ``replicate`` guarantees in the reference, main_DataParallel.py:609): one collective for the
+        floating-point state, one for the integer buffers."""
+        if not self.collective:
+            return
+        with torch.no_grad():
+            for pick in (lambda t: t.is_floating_point(), lambda t: not t.is_floating_point()):
+                ts = [t for t in list(module.parameters()) + list(module.buffers()) if pick(t)]
+                if not ts:
+                    continue
+                flat = torch.cat([t.detach().reshape(-1) for t in ts])
+                dist.broadcast(flat, src=src)
+                off = 0
+                for t in ts:
+                    n = t.numel()
+                    t.copy_(flat[off:off + n].view(t.shape))
+                    off += n
+
+    def _exchange(self, flat_g: torch.Tensor) -> None:
+        dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
+        get_backend().scale_(flat_g, 1.0 / self.world)
+
     def average_(self, flat_g: torch.Tensor) -> None:
+        """Sum over ranks / world size, complete (in stream order) when the call returns."""
         if not self.collective:
             return
         if self.side is not None:
             main = torch.cuda.current_stream(flat_g.device)
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
-                dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
+                self._exchange(flat_g)
             main.wait_stream(self.side)
         else:
-            dist.all_reduce(flat_g, op=dist.ReduceOp.SUM)
-        get_backend().axpby(1.0 / self.world, flat_g, 0.0, flat_g)
+            self._exchange(flat_g)
+
+    def average_and_step(self, opt) -> None:
+        """Average ``opt.flat_g`` over the ranks, then ``opt.step()``.  On a GPU job both run on the side
+        stream, behind everything the main stream has queued so far, and the main stream carries on: work
+        that does not read the parameters of ``opt`` (the D-step's first two decoder passes after the
+        encoder update) overlaps the exchange and the update.  ``wait()`` must be called before the
+        updated parameters, or the gradient buffer, are touched again."""
+        if not self.collective or self.side is None:
+            self.average_(opt.flat_g)
+            opt.step()
+            return
+        main = torch.cuda.current_stream(opt.flat_g.device)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self._exchange(opt.flat_g)
+            opt.step()
+            self._pending = self.side.record_event()
+
+    def wait(self) -> None:
+        if self._pending is not None:
+            torch.cuda.current_stream().wait_event(self._pending)
+            self._pending = None
+
+    def average_stats_(self, stats: torch.Tensor) -> torch.Tensor:
+        """Batch-mean statistics of a rank -> means over the global batch (for logging)."""
+        if self.collective:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+            stats /= self.world
+        return stats

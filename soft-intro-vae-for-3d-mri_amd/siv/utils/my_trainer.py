@@ -11,8 +11,12 @@ Deliberate differences from the reference, all host-side:
 * the ten per-iteration ``.item()`` host syncs are one stacked device-to-host copy;
 * slice images (``save_image``, matplotlib + skimage) are not produced;
 * output sub-directories are created instead of being required to pre-exist;
-* with WORLD_SIZE > 1 the encoder / decoder gradients are averaged over ranks before
-  each optimiser step (replaces main_DataParallel.py's nn.DataParallel).
+* with WORLD_SIZE > 1 (one process per GPU) the trainer does what main_DataParallel.py's nn.DataParallel
+  does inside one process: every rank starts from rank 0's parameters and buffers, each batch the loader
+  yields is the GLOBAL batch and rank r trains on its slice of it (the batch size must be a multiple of
+  the world size), the encoder / decoder gradients are averaged over ranks before each optimiser step,
+  logged statistics are means over the global batch, BatchNorm statistics stay per replica, and only
+  rank 0 writes checkpoints and logs.
 """
 from __future__ import annotations
 
@@ -129,8 +133,7 @@ class SoftIntroStep:
             ops.sse_per_sample(rec, rec_rec), ops.kl_per_sample(rec_mu, rec_logvar), scale, br, bn, bk)
         self.opt_e.zero_grad()
         lossE.backward()
-        self.sync.average_(self.opt_e.flat_g)
-        self.opt_e.step()
+        self.sync.average_and_step(self.opt_e)       # multi-GPU: exchange + update run beside the next two decodes
         stats_e = (lossE.detach(), se[0], se[1], se[2])      # lossE, kl_real, exp_elbo_rec, exp_elbo_fake
         z = z.detach()
         del fake, rec, rec_rec, rec_fake, lossE
@@ -142,6 +145,7 @@ class SoftIntroStep:
             p.requires_grad = True
         fake = model.decode(noise_batch)
         rec = model.decode(z)
+        self.sync.wait()                             # the encoder update is complete from here on
         rec_mu, rec_logvar = model.encode(rec)
         z_rec = model.reparameterize(rec_mu, rec_logvar)
         fake_mu, fake_logvar = model.encode(fake)
@@ -154,11 +158,12 @@ class SoftIntroStep:
             ops.sse_per_sample(fake.detach(), rec_fake), scale, br, bk, gr)
         self.opt_d.zero_grad()
         lossD.backward()
-        self.sync.average_(self.opt_d.flat_g)
-        self.opt_d.step()
+        self.sync.average_and_step(self.opt_d)
+        self.sync.wait()
         fake_kl, rec_kl, loss_rec = sd[0], sd[1], sd[2]
         # one device->host copy serves every statistic the trainer logs
-        return torch.stack([stats_e[0], lossD.detach(), stats_e[1], fake_kl, rec_kl, loss_rec, stats_e[2], stats_e[3]])
+        return self.sync.average_stats_(
+            torch.stack([stats_e[0], lossD.detach(), stats_e[1], fake_kl, rec_kl, loss_rec, stats_e[2], stats_e[3]]))
 
 
 STAT_NAMES = ("lossE", "lossD", "kl_real", "fake_kl", "rec_kl", "loss_rec", "exp_elbo_rec", "exp_elbo_fake")
@@ -212,6 +217,7 @@ def train_soft_intro_vae(
     if pretrained_path is not None:
         load_model(model, pretrained_path, device)
     model.apply(init_weights_he)                                         # :202 (after the load: quirk kept)
+    sync.broadcast_(model)                                               # every rank starts from rank 0's replica
     optimizer_e = FlatAdam(model.encoder.parameters(), lr=2e-4)           # :183
     optimizer_d = FlatAdam(model.decoder.parameters(), lr=2e-4)           # :184
     e_scheduler = MultiStepLR(optimizer_e, milestones=(350,), gamma=0.1)  # :185
@@ -235,7 +241,7 @@ def train_soft_intro_vae(
         nvox = 1
         st = None
         for batch, labels in train_loader:
-            real_batch = batch.to(device)
+            real_batch = sync.shard(batch.to(device))                     # rank r trains on its slice of the batch
             noise_batch = _noise(model, real_batch.size(0), real_batch.shape[2:], device)   # :238
             nvox = int(np.prod(real_batch.shape[2:]))
             st = dict(zip(STAT_NAMES, step(real_batch, noise_batch).cpu().tolist()))
@@ -393,6 +399,7 @@ def train_ResNetVAE(
     net = net.to(device)
     print(f"mse_weight={mse_w}  kl_weight={kl_w}")
     net = net.apply(init_weights_he_relu)
+    sync.broadcast_(net)
     optimizer = FlatAdam(net.parameters(), lr)
     train_losses, val_losses = [], []
     train_mse_losses, train_kl_losses, val_mse_losses, val_kl_losses = [], [], [], []
@@ -402,14 +409,14 @@ def train_ResNetVAE(
         train_run_mse = train_run_kl = train_run_loss = 0.0
         net.train()
         for inputs, labels in train_loader:
-            inputs = inputs.to(device)
+            inputs = sync.shard(inputs.to(device))
             optimizer.zero_grad()
             x_re, mu, logvar = net.forward(inputs)
             loss, mse, kl = lossf.normal_loss(x_re, mu, logvar, inputs, mse_w, kl_w)
             loss.backward()
             sync.average_(optimizer.flat_g)
             optimizer.step()
-            l, m, k = torch.stack([loss.detach(), mse.detach(), kl.detach()]).cpu().tolist()
+            l, m, k = sync.average_stats_(torch.stack([loss.detach(), mse.detach(), kl.detach()])).cpu().tolist()
             train_run_loss += l
             train_run_mse += m
             train_run_kl += k

@@ -68,6 +68,7 @@ def train_soft_intro_vae(
     if pretrained_path is not None:
         load_model(model, pretrained_path, device)
     model.apply(init_weights_he)                                         # :187
+    sync.broadcast_(model)                                               # every rank starts from rank 0's replica
     optimizer_e = FlatAdam(model.encoder.parameters(), lr=2e-4)           # :165
     optimizer_d = FlatAdam(model.decoder.parameters(), lr=2e-4)           # :166
     e_scheduler = MultiStepLR(optimizer_e, milestones=(350,), gamma=0.1)
@@ -88,8 +89,8 @@ def train_soft_intro_vae(
         batch_kls_real, batch_kls_fake, batch_kls_rec, batch_rec_errs = [], [], [], []
         st = None
         for batch, labels in train_loader:
-            noise_batch = _noise(model, batch.size(0), device)            # :218 (drawn before the batch moves)
-            real_batch = batch.to(device)
+            real_batch = sync.shard(batch.to(device))                     # rank r trains on its slice of the batch
+            noise_batch = _noise(model, real_batch.size(0), device)       # :218
             st = dict(zip(STAT_NAMES, step(real_batch, noise_batch).cpu().tolist()))
             train_lossE += st["lossE"]
             train_lossD += st["lossD"]

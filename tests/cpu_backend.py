@@ -199,6 +199,10 @@ class CpuCheckerBackend:
         gen = torch.Generator().manual_seed((seed * 7919 + stream_id) % (2 ** 63))
         return (torch.rand(tuple(shape), generator=gen) >= p).to(torch.uint8)
 
+    def scale_(self, x, a):
+        with torch.no_grad():
+            x.mul_(a)
+
     def axpby(self, a, x, b, y):
         with torch.no_grad():
             if b == 0.0:

@@ -65,6 +65,32 @@ def _worker(rank, world, port, out):
     sd, real, noise, scale = _load_sd()
     res = _one_rank_step(sd, sync.shard(real), sync.shard(noise), scale, rank, sync)
     out[rank] = [t.numpy() for t in res]
+    # initial broadcast: ranks that were initialised differently end up with rank 0's replica
+    import siv.models.models as models
+    torch.manual_seed(1000 + rank)
+    net = models.SoftIntroVAE(*CFG)
+    with torch.no_grad():
+        for b in net.buffers():
+            if b.dtype == torch.int64:
+                b.fill_(5 + rank)
+    sync.broadcast_(net)
+    out[f"bcast{rank}"] = {k: v.numpy().copy() for k, v in net.state_dict().items()}
+    # the trainers shard the loader's (global) batches themselves and log global-batch means
+    import siv.rng as srng
+    import siv.utils.my_trainer as trainer
+    from oracle import siv_oracle as O
+    import tempfile
+    gen = torch.Generator().manual_seed(7)
+    loader = [(torch.rand(4, 1, 16, 24, 16, generator=gen), torch.zeros(4)) for _ in range(2)]
+    torch.manual_seed(2000 + rank)                                       # different start on every rank
+    net = models.SoftIntroVAE(*CFG)
+    with tempfile.TemporaryDirectory() as d, srng.use_rng(srng.ReplayRng(O.Draws(seed=300 + rank))):
+        lists = trainer.train_soft_intro_vae(net, loader, loader[:1], 1, 2e-4, torch.device("cpu"), d + "/",
+                                             1.0, 1024.0, 0.75)
+        files = sorted(os.listdir(d))
+    out[f"train{rank}"] = (np.array(lists[0]), np.array(lists[1]),
+                           {k: v.numpy().copy() for k, v in net.state_dict().items() if "running" not in k
+                            and "num_batches" not in k}, files)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,6 +100,30 @@ class _NoSync:
 
     def average_(self, flat_g):
         pass
+
+    def average_and_step(self, opt):
+        opt.step()
+
+    def wait(self):
+        pass
+
+    def average_stats_(self, t):
+        return t
+
+
+class _InjectSync(_NoSync):
+    """Sequential emulation of the exchange: records this shard's gradient of the n-th optimiser step and
+    replaces it with the given all-shard average (None = keep)."""
+
+    def __init__(self, inject):
+        self.inject, self.seen = list(inject), []
+
+    def average_and_step(self, opt):
+        self.seen.append(opt.flat_g.clone())
+        avg = self.inject[len(self.seen) - 1]
+        if avg is not None:
+            opt.flat_g.copy_(avg)
+        opt.step()
 
 
 def test_two_rank_gloo_matches_sequential_shards():
@@ -90,16 +140,54 @@ def test_two_rank_gloo_matches_sequential_shards():
     # both ranks hold the same averaged gradients and the same weights after the step
     for a, b in zip(r0, r1):
         np.testing.assert_array_equal(a, b)
-    # emulate the encoder update by hand: per-shard gradients, averaged
+    # emulate the exchange by hand, shard after shard: encoder gradients first (they do not depend on the
+    # exchange), then -- with the averaged encoder gradient injected, so that the D-step runs on the same
+    # updated encoder as in the two-rank job -- the decoder gradients, then the final weights
     sb.set_backend(CpuCheckerBackend())
     try:
         sd, real, noise, scale = _load_sd()
-        gE = [_one_rank_step(sd, real[2 * r:2 * r + 2], noise[2 * r:2 * r + 2], scale, r, _NoSync())[0]
-              for r in range(2)]
+        shard = lambda r: (real[2 * r:2 * r + 2], noise[2 * r:2 * r + 2])
+        gE = [_one_rank_step(sd, *shard(r), scale, r, _NoSync())[0] for r in range(2)]
+        avgE = (gE[0] + gE[1]) / 2
+        gD = []
+        for r in range(2):
+            sy = _InjectSync([avgE, None])
+            _one_rank_step(sd, *shard(r), scale, r, sy)
+            gD.append(sy.seen[1])
+        avgD = (gD[0] + gD[1]) / 2
+        final = _one_rank_step(sd, *shard(0), scale, 0, _InjectSync([avgE, avgD]))
     finally:
         sb.set_backend(None)
-    np.testing.assert_allclose(r0[0], ((gE[0] + gE[1]) / 2).numpy(), rtol=1e-5,
-                               atol=1e-5 * float(np.abs(r0[0]).max()))
+    tol = lambda a: dict(rtol=1e-5, atol=1e-5 * float(np.abs(a).max()))
+    np.testing.assert_allclose(r0[0], avgE.numpy(), **tol(r0[0]))                 # encoder gradient buffer
+    np.testing.assert_allclose(r0[1], avgD.numpy(), **tol(r0[1]))                 # decoder gradient buffer
+    # weights after the step: Adam's first update is lr * sign(g) -- tight where |g| is clear of rounding noise,
+    # +-2 lr elsewhere (the two-rank sum and the emulation add the shard gradients in different orders)
+    from tests.parity import check_params_after_adam
+    check_params_after_adam(r0[2], final[2], avgE, 2e-4, "encoder weights after the step")
+    check_params_after_adam(r0[3], final[3], avgD, 2e-4, "decoder weights after the step")
+
+    # broadcast: rank 1 (seeded differently) now holds rank 0's parameters and buffers
+    b0, b1 = out["bcast0"], out["bcast1"]
+    torch.manual_seed(1000)
+    import siv.models.models as models
+    want = models.SoftIntroVAE(*CFG).state_dict()
+    for k in b0:
+        np.testing.assert_array_equal(b0[k], b1[k], err_msg=k)
+        if b0[k].dtype == np.int64:
+            assert int(b0[k]) == 5, k
+        else:
+            np.testing.assert_array_equal(b0[k], want[k].numpy(), err_msg=k)
+
+    # trainer: ranks started from different weights, trained on different halves of each batch, and end with
+    # identical weights and identical (global-mean) loss lists; only rank 0 wrote checkpoints and logs
+    t0, t1 = out["train0"], out["train1"]
+    np.testing.assert_array_equal(t0[0], t1[0])
+    np.testing.assert_array_equal(t0[1], t1[1])
+    assert np.isfinite(t0[0]).all() and np.isfinite(t0[1]).all()
+    for k in t0[2]:
+        np.testing.assert_array_equal(t0[2][k], t1[2][k], err_msg=k)
+    assert "loss.txt" in t0[3] and "prams" in t0[3] and "loss.txt" not in t1[3]
 
 
 def test_shard_rejects_indivisible_batch():

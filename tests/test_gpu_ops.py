@@ -388,8 +388,11 @@ def test_axpby(B):
     yd = dev(y.clone())
     B.axpby(0.5, dev(x), 2.0, yd)
     check(yd, 0.5 * x + 2.0 * y, "axpby")
-    B.axpby(0.25, yd, 0.0, yd)                                   # in-place scaling
+    B.scale_(yd, 0.25)                                           # in-place scaling
     check(yd, 0.25 * (0.5 * x + 2.0 * y), "scale")
+    import siv._lib as L
+    with pytest.raises(L.SivError):                              # the out-of-place kernel rejects aliased buffers
+        B.axpby(0.25, yd, 0.0, yd)
 
 
 @pytest.mark.parametrize("b,k,o", [(2, 1200, 32), (8, 19200, 1200), (8, 600, 19200), (3, 37, 5), (11, 130, 64)])
