@@ -90,7 +90,10 @@ int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bias, float* 
  * after nn.Conv3d, models/models.py:17-18,21-22,55-56,59-60; models/mymodel.py:56-57 etc.) in one
  * call: where the kernel family allows it the statistics are accumulated in the convolution's
  * epilogue and y is not read again.  mean / var / running_* / num_batches_tracked as in
- * siv_bn_stats. */
+ * siv_bn_stats.  The epilogue sums are unshifted fp32 per brick (fp64 across bricks): exact to 1e-4 of
+ * the variance while |channel mean| stays within a few tens of standard deviations (fp32 cancellation
+ * grows with (mean/std)^2 / sqrt(bricks); tested at 5, a bias-free convolution of normalised activations
+ * sits near 1); siv_bn_stats, which shifts by a sample first, has no such limit. */
 int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const float* bias, float* y,
                               int N, int D, int H, int W, int Cin, int Cout, int ups,
                               float* mean, float* var, float* running_mean, float* running_var,

@@ -195,3 +195,50 @@ def test_z1200_step_at_full_size_matches_reference():
         elif not k.endswith(cancelled):
             rg = ref["gradE" if k.startswith("encoder.") else "gradD"][k]
             check_params_after_adam(v, sd[k], rg, hp.lr, k)
+
+
+def test_full_resolution_160_model_matches_oracle():
+    """models.soft_intro_vae_z1200(full_resolution=True) -- the z=1200 stack with one more stride-2 stage for
+    160x192x160 volumes (1.26 GB activations per sample at full resolution): evaluation-mode forward of one
+    volume against the oracle at 1e-4, then one training iteration with the device generator (finite
+    losses, 10x12x10 latent, every used parameter moved)."""
+    import siv.models.models as models
+    import siv.rng as srng
+    import siv.utils.my_trainer as trainer
+    from siv.optim import FlatAdam
+    dims = (160, 192, 160)
+    torch.manual_seed(82)
+    net = models.soft_intro_vae_z1200(full_resolution=True)
+    torch.manual_seed(77)
+    net.apply(trainer.init_weights_he)
+    assert net.latent_shape(1, dims) == (1, 1, 10, 12, 10)
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.running_mean.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+                m.running_var.copy_(0.5 + torch.rand(m.bias.shape, generator=gen))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.rand(1, 1, *dims, generator=gen)
+    cfg = O.Cfg(64, models.BLOCKS_Z1200_160)
+    with torch.no_grad():
+        mu_r, lv_r = O.encode(x, sd, cfg, None, False)
+        z_r = O.reparameterize(mu_r, lv_r, None, True)
+        x_r = O.decode(z_r, sd, cfg, None, False)
+    net = net.to("cuda").eval()
+    with torch.no_grad():
+        mu, lv = net.encode(x.cuda())
+        z = net.reparameterize(mu, lv, True)
+        xe = net.decode(z)
+    for a, b, n in ((mu, mu_r, "mu"), (lv, lv_r, "logvar"), (z, z_r, "z"), (xe, x_r, "x_re")):
+        check_max(a, b, n)
+    del xe, x_r
+    net.train()
+    opt_e, opt_d = FlatAdam(net.encoder.parameters(), lr=2e-4), FlatAdam(net.decoder.parameters(), lr=2e-4)
+    step = trainer.SoftIntroStep(net, opt_e, opt_d)
+    w0 = opt_e.flat_p.clone()
+    srng.manual_seed(5, 0)
+    st = dict(zip(trainer.STAT_NAMES, step(x.cuda(), srng.get_rng().eps((1, 1, 10, 12, 10), "cuda")).cpu().tolist()))
+    assert all(np.isfinite(v) for v in st.values()), st
+    moved = float(((opt_e.flat_p - w0).abs() > 0).float().mean())
+    assert moved > 0.9, moved

@@ -617,3 +617,27 @@ def test_packed_weight_cache(B):
             assert hits() == h2
         finally:
             B.set_conv_path(0)
+
+
+@pytest.mark.parametrize("path,ups", [(6, 1), (0, 2), (3, 1)])
+def test_fused_bn_statistics_with_large_channel_means(B, path, ups):
+    """The kernels that emit the BatchNorm sums from their epilogue accumulate UNSHIFTED fp32 sums per brick
+    (combined in fp64); siv_bn_stats shifts by a sample first.  With every channel mean several standard
+    deviations away from zero (a nearly constant input through all-positive weights; the zero padding at
+    the volume border is what keeps the ratio near 5) the two still agree at 1e-4 of the largest variance."""
+    gen = torch.Generator().manual_seed(path + ups)
+    D, H, W = 16, 16, 16
+    x = rnd(gen, 2, 64, D // ups, H // ups, W // ups) * 0.05 + 1.0        # nearly constant input: output mean >> std
+    w = rnd(gen, 64, 64, 3, 3, 3, scale=0.02) + 0.01
+    B.set_conv_path(path)
+    try:
+        y, mean, var = B.conv3d_k3_fwd_stats(dev(x), dev(w), None, ups, None, None, None, 0.1)
+    finally:
+        B.set_conv_path(0)
+    m2, v2 = B.bn_stats(y, None, None, None, 0.1)
+    yd = y.double()
+    ratio = float((yd.mean(dim=(0, 2, 3, 4)).abs() / yd.std(dim=(0, 2, 3, 4))).max())
+    assert ratio > 4, ratio
+    check(mean, m2, "mean")
+    check(var, yd.var(dim=(0, 2, 3, 4), unbiased=False).float(), "variance (fused) vs float64")
+    check(var, v2, "variance (fused) vs siv_bn_stats")

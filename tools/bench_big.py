@@ -33,7 +33,8 @@ def main():
     from siv.optim import FlatAdam
     dev = torch.device("cuda")
     torch.manual_seed(82)
-    net = models.SoftIntroVAE(*MODEL)
+    net = models.soft_intro_vae_z1200(full_resolution=True)
+    assert net.encoder.block_setting == MODEL[1]
     torch.manual_seed(77)
     net.apply(trainer.init_weights_he)
     net = net.to(dev).train()
