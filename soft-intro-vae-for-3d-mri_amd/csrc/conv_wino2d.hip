@@ -30,6 +30,20 @@
 
 namespace siv {
 
+// SIV_W2STAMP (diagnostic build only, tools/ubench/wino2d_stamps.hip): lane 0 of every wave of the first
+// blocks records the shader clock at block entry, before and after every barrier of the chunk loop and at
+// block exit, into a buffer of its own that nothing else reads.
+#ifdef SIV_W2STAMP
+__device__ unsigned long long w2_stamps[2048 * 8 * 32];
+#define SIV_STAMP(i)                                                                                         \
+    do {                                                                                                     \
+        if (lane == 0 && blockIdx.x < 2048 && (i) < 32)                                                      \
+            w2_stamps[((long)blockIdx.x * 8 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();              \
+    } while (0)
+#else
+#define SIV_STAMP(i)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct W2Cfg {
@@ -69,6 +83,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int ph = wave & 3, wn = wave >> 2;
+    SIV_STAMP(0);
 
     int b = blockIdx.x;
     if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
@@ -172,7 +187,9 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
         for (int piece = 0; piece < 8; ++piece) stage_piece(piece, lds);
     }
     if (!(SIV_W2EXP & 17)) load_patch((nchunk > 1 ? 1 : 0) * C::CK);
+    SIV_STAMP(1);
     __syncthreads();
+    SIV_STAMP(2);
 
     for (int cc = 0; cc < nchunk; ++cc) {
         const float* cur = lds + (cc & 1) * C::V_FLOATS;
@@ -226,7 +243,9 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
         // the patch of the chunk after next goes out right behind the last pieces of this one: its
         // issue overlaps the wait at the barrier and it has a chunk and a half to arrive
         if (!(SIV_W2EXP & 17)) load_patch((cc + 2 < nchunk ? cc + 2 : cc) * C::CK);
+        SIV_STAMP(3 + 2 * cc);
         if (!(SIV_W2EXP & 2)) __syncthreads();
+        SIV_STAMP(4 + 2 * cc);
     }
 
     // ---- output transform and store ----
@@ -276,6 +295,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             }
         }
     }
+    SIV_STAMP(29);
     if (stat_part) {
         // lanes with equal cq (bits 3..5 differ) hold the same four channels
 #pragma unroll
@@ -300,6 +320,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             if (co0 + c < Cout) stat_part[((long)blockIdx.x * 2 + k) * Cout + co0 + c] = s;
         }
     }
+    SIV_STAMP(30);
 }
 
 // Packed, transformed weights: wp[ct][cc][kd*16 + ph*4 + pw][co (64)][ci (8)] = (G g_kd G^T)[ph][pw].
