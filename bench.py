@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="volumes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="single GPU: capture the iteration in a HIP graph and replay it (the per-kernel "
+                         "event timing of the roofline fields is then taken from two eager iterations)")
     ap.add_argument("--split-bf16", action="store_true",
                     help="also time the opt-in conv path 5 (fp32 products from bf16 triples); never the headline")
     args = ap.parse_args()
@@ -202,10 +205,12 @@ def main():
         lambda x, w, *r: w.shape[0] == 1 and w.shape[1] == 64 and tuple(x.shape[2:]) == DIMS,
         lambda x, w, *r: (x.numel() + x.numel() // 64) * 4)
 
+    graphed = None
+
     def one_step(i):
         real = batches[i % n_batches]
         noise = srng.get_rng().eps(net.latent_shape(real.size(0), DIMS), device)
-        return step(real, noise)
+        return (graphed or step)(real, noise)
 
     multi = dist.is_initialized()       # world > 1, or a forced one-rank rehearsal of the RCCL path
 
@@ -217,7 +222,17 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     barrier()
-    recording["on"] = True
+    if args.graph and not multi:
+        # kernel-level timing needs individually launched kernels: two eager iterations first
+        recording["on"] = True
+        for i in range(2):
+            one_step(i)
+        barrier()
+        recording["on"] = False
+        graphed = trainer.GraphedSoftIntroStep(step, batches[0].shape, net.latent_shape(args.batch, DIMS), device)
+        one_step(0)
+        barrier()
+    recording["on"] = graphed is None
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
@@ -313,7 +328,8 @@ def main():
                                    "SoftIntroVAE(64,[[64,1,2],[128,1,2],[256,2,2]]), E-step + D-step + 2 Adam updates",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}" if world > 1 else "single",
-                       "rng": "device Philox (dropout, eps, noise)"},
+                       "rng": "device Philox (dropout, eps, noise)",
+                       "launch": "HIP graph replay" if graphed is not None else "kernel by kernel"},
             "host_enqueue_ms_per_step": round(1000.0 * host_elapsed / args.steps, 2),
             "roofline": roof,
             "roofline_step": roof_step,

@@ -300,6 +300,15 @@ int siv_sintro_loss_d_bwd(const float* g, int B, float scale, float beta_rec, fl
 int siv_adam_step(float* p, const float* g, float* m, float* v, long n,
                   float lr, float beta1, float beta2, float eps, int step, siv_stream_t stream);
 
+/* siv_adam_step with the learning rate (float) and the 1-based step count (int64) read from device
+ * memory at execution time, so that a launch captured in a HIP graph keeps following the schedule
+ * (utils/my_trainer.py:185-186, 502-503) and the bias corrections on every replay.
+ * siv_counter_add: *counter += inc on the stream (advances such a step count, or the random epoch below,
+ * from inside a captured sequence). */
+int siv_adam_step_at(float* p, const float* g, float* m, float* v, long n, const float* lr,
+                     float beta1, float beta2, float eps, const int64_t* step, siv_stream_t stream);
+int siv_counter_add(int64_t* counter, int64_t inc, siv_stream_t stream);
+
 /* ---- device random numbers -------------------------------------------------------
  * Philox-4x32-10 counter RNG keyed by (seed, stream_id); element i of a call uses
  * counter i/4.  Replaces torch.randn / torch.randn_like (utils/my_trainer.py:238,
@@ -308,6 +317,13 @@ int siv_adam_step(float* p, const float* g, float* m, float* v, long n,
 int siv_randn(float* out, long n, uint64_t seed, uint64_t stream_id, siv_stream_t stream);
 int siv_dropout_keep(uint8_t* keep, long n, float p, uint64_t seed, uint64_t stream_id,
                      siv_stream_t stream);
+/* The same with stream_id + (*epoch << 20) as the stream id, *epoch (uint64, device memory, may be NULL)
+ * read at execution time: launches captured in a HIP graph draw fresh numbers on every replay once
+ * the epoch has been advanced (siv_counter_add). */
+int siv_randn_at(float* out, long n, uint64_t seed, uint64_t stream_id, const uint64_t* epoch,
+                 siv_stream_t stream);
+int siv_dropout_keep_at(uint8_t* keep, long n, float p, uint64_t seed, uint64_t stream_id,
+                        const uint64_t* epoch, siv_stream_t stream);
 
 /* ---- helpers ------------------------------------------------------------------------ */
 /* y = a*x + b*y elementwise (gradient accumulation on device); x and y must not overlap. */

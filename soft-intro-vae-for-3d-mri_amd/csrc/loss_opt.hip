@@ -196,6 +196,29 @@ __global__ __launch_bounds__(256) void adam_k(float* __restrict__ p, const float
     }
 }
 
+// Adam whose learning rate and step count live in device memory: a captured launch (HIP graph) then
+// follows the schedule and the bias corrections from replay to replay.
+__global__ __launch_bounds__(256) void adam_dev_k(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ m, float* __restrict__ v, long n,
+                                                  float b1, float b2, float eps, const float* __restrict__ lr,
+                                                  const long long* __restrict__ step) {
+    const double t = (double)*step;
+    const float step_size = (float)((double)*lr / (1.0 - pow((double)b1, t)));
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+__global__ void counter_add_k(long long* c, long long inc) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *c += inc;
+}
+
 __global__ __launch_bounds__(256) void scale_k(float a, float* x, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         x[i] *= a;
@@ -232,8 +255,12 @@ __device__ __forceinline__ float u01(uint32_t r) {  // (0,1]
     return ((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }
 
+// epoch (optional, device memory): added to the stream id in steps of 2^20, so that a launch captured in a
+// HIP graph draws fresh numbers on every replay once the counter has been advanced
+#define SIV_EPOCH_STRIDE (1ull << 20)
 __global__ __launch_bounds__(256) void randn_k(float* __restrict__ out, long n, uint64_t seed,
-                                               uint64_t sid) {
+                                               uint64_t sid, const unsigned long long* __restrict__ epoch) {
+    if (epoch) sid += *epoch * SIV_EPOCH_STRIDE;
     const long quads = (n + 3) / 4;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < quads;
          q += (long)gridDim.x * blockDim.x) {
@@ -247,7 +274,9 @@ __global__ __launch_bounds__(256) void randn_k(float* __restrict__ out, long n, 
     }
 }
 __global__ __launch_bounds__(256) void dropout_keep_k(uint8_t* __restrict__ keep, long n, float p,
-                                                      uint64_t seed, uint64_t sid) {
+                                                      uint64_t seed, uint64_t sid,
+                                                      const unsigned long long* __restrict__ epoch) {
+    if (epoch) sid += *epoch * SIV_EPOCH_STRIDE;
     const long quads = (n + 3) / 4;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < quads;
          q += (long)gridDim.x * blockDim.x) {
@@ -408,17 +437,41 @@ extern "C" int siv_adam_step(float* p, const float* g, float* m, float* v, long 
     SIV_CHECK_LAUNCH("adam_step");
     return SIV_OK;
 }
-extern "C" int siv_randn(float* out, long n, uint64_t seed, uint64_t stream_id, siv_stream_t stream) {
+extern "C" int siv_randn_at(float* out, long n, uint64_t seed, uint64_t stream_id, const uint64_t* epoch,
+                            siv_stream_t stream) {
     SIV_CHECK_ARG(out && n > 0, "randn: bad argument");
-    randn_k<<<ew_grid((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(out, n, seed, stream_id);
+    randn_k<<<ew_grid((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(out, n, seed, stream_id,
+                                                                  (const unsigned long long*)epoch);
     SIV_CHECK_LAUNCH("randn");
+    return SIV_OK;
+}
+extern "C" int siv_randn(float* out, long n, uint64_t seed, uint64_t stream_id, siv_stream_t stream) {
+    return siv_randn_at(out, n, seed, stream_id, nullptr, stream);
+}
+extern "C" int siv_dropout_keep_at(uint8_t* keep, long n, float p, uint64_t seed, uint64_t stream_id,
+                                   const uint64_t* epoch, siv_stream_t stream) {
+    SIV_CHECK_ARG(keep && n > 0 && p >= 0.f && p < 1.f, "dropout_keep: bad argument");
+    dropout_keep_k<<<ew_grid((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(keep, n, p, seed, stream_id,
+                                                                         (const unsigned long long*)epoch);
+    SIV_CHECK_LAUNCH("dropout_keep");
     return SIV_OK;
 }
 extern "C" int siv_dropout_keep(uint8_t* keep, long n, float p, uint64_t seed, uint64_t stream_id,
                                 siv_stream_t stream) {
-    SIV_CHECK_ARG(keep && n > 0 && p >= 0.f && p < 1.f, "dropout_keep: bad argument");
-    dropout_keep_k<<<ew_grid((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(keep, n, p, seed, stream_id);
-    SIV_CHECK_LAUNCH("dropout_keep");
+    return siv_dropout_keep_at(keep, n, p, seed, stream_id, nullptr, stream);
+}
+extern "C" int siv_adam_step_at(float* p, const float* g, float* m, float* v, long n, const float* lr,
+                                float beta1, float beta2, float eps, const int64_t* step, siv_stream_t stream) {
+    SIV_CHECK_ARG(p && g && m && v && lr && step && n > 0, "adam_step_at: bad argument");
+    adam_dev_k<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, beta1, beta2, eps, lr,
+                                                            (const long long*)step);
+    SIV_CHECK_LAUNCH("adam_step_at");
+    return SIV_OK;
+}
+extern "C" int siv_counter_add(int64_t* counter, int64_t inc, siv_stream_t stream) {
+    SIV_CHECK_ARG(counter != nullptr, "counter_add: null pointer");
+    counter_add_k<<<1, 64, 0, (hipStream_t)stream>>>((long long*)counter, (long long)inc);
+    SIV_CHECK_LAUNCH("counter_add");
     return SIV_OK;
 }
 extern "C" int siv_scale(float a, float* x, long n, siv_stream_t stream) {

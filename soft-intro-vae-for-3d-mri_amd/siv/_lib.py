@@ -56,6 +56,10 @@ SIGNATURES = {
     "siv_sintro_loss_d_fwd": [_f, _f, _f, _f, _f, _i, _fl, _fl, _fl, _fl, _f, _f],
     "siv_sintro_loss_d_bwd": [_f, _i, _fl, _fl, _fl, _fl, _f, _f],
     "siv_adam_step": [_f, _f, _f, _f, _l, _fl, _fl, _fl, _fl, _i, _f],
+    "siv_adam_step_at": [_f, _f, _f, _f, _l, _f, _fl, _fl, _fl, _f, _f],
+    "siv_counter_add": [_f, C.c_int64, _f],
+    "siv_randn_at": [_f, _l, _u64, _u64, _f, _f],
+    "siv_dropout_keep_at": [_f, _l, _fl, _u64, _u64, _f, _f],
     "siv_randn": [_f, _l, _u64, _u64, _f],
     "siv_dropout_keep": [_f, _l, _fl, _u64, _u64, _f],
     "siv_axpby": [_fl, _f, _fl, _f, _l, _f],

@@ -557,18 +557,30 @@ class HipBackend:
                                           float(beta2), float(eps), int(step), self._stream(p)),
                    "siv_adam_step")
 
-    def randn(self, shape, device, seed: int, stream_id: int):
+    def adam_step_at(self, p, g, m, v, lr_dev, beta1, beta2, eps, step_dev) -> None:
+        """Adam with learning rate (float32 tensor) and step count (int64 tensor) in device memory."""
+        self._check_dev(p, g, m, v, step_dev)
+        assert lr_dev.is_cuda and lr_dev.dtype == torch.float32 and step_dev.dtype == torch.int64
+        _lib.check(self.lib.siv_adam_step_at(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(lr_dev), float(beta1),
+                                             float(beta2), float(eps), _p(step_dev), self._stream(p)),
+                   "siv_adam_step_at")
+
+    def counter_add(self, counter, inc: int) -> None:
+        assert counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1
+        _lib.check(self.lib.siv_counter_add(_p(counter), int(inc), self._stream(counter)), "siv_counter_add")
+
+    def randn(self, shape, device, seed: int, stream_id: int, epoch=None):
         out = torch.empty(tuple(shape), device=device, dtype=torch.float32)
         self._check_dev(out)
-        _lib.check(self.lib.siv_randn(_p(out), out.numel(), seed & (2 ** 64 - 1), stream_id & (2 ** 64 - 1),
-                                      self._stream(out)), "siv_randn")
+        _lib.check(self.lib.siv_randn_at(_p(out), out.numel(), seed & (2 ** 64 - 1), stream_id & (2 ** 64 - 1),
+                                         _p(epoch), self._stream(out)), "siv_randn")
         return out
 
-    def dropout_keep(self, shape, device, p: float, seed: int, stream_id: int):
+    def dropout_keep(self, shape, device, p: float, seed: int, stream_id: int, epoch=None):
         out = torch.empty(tuple(shape), device=device, dtype=torch.uint8, memory_format=CL3D)
         self._check_dev(out)
-        _lib.check(self.lib.siv_dropout_keep(_p(out), out.numel(), float(p), seed & (2 ** 64 - 1),
-                                             stream_id & (2 ** 64 - 1), self._stream(out)),
+        _lib.check(self.lib.siv_dropout_keep_at(_p(out), out.numel(), float(p), seed & (2 ** 64 - 1),
+                                                stream_id & (2 ** 64 - 1), _p(epoch), self._stream(out)),
                    "siv_dropout_keep")
         return out
 

@@ -40,9 +40,10 @@ class FlatAdam:
         if not self.params:
             raise ValueError("FlatAdam got an empty parameter list")
         dev = self.params[0].device
-        self.lr, self.betas, self.eps = float(lr), tuple(betas), float(eps)
-        self.base_lr = self.lr
+        self._lr, self.betas, self.eps = float(lr), tuple(betas), float(eps)
+        self.base_lr = self._lr
         self.step_count = 0
+        self.dev_lr = self.dev_step = None     # device-resident learning rate / step count (graph capture)
         self.offsets = []
         off = 0
         for p in self.params:
@@ -69,6 +70,24 @@ class FlatAdam:
         if dev.type == "cuda" and hasattr(B, "register_weights"):
             B.register_weights(self.flat_p)       # packed convolution weights are kept between steps
 
+    @property
+    def lr(self) -> float:
+        return self._lr
+
+    @lr.setter
+    def lr(self, value: float) -> None:
+        self._lr = float(value)
+        if self.dev_lr is not None:
+            self.dev_lr.fill_(self._lr)
+
+    def use_device_state(self) -> None:
+        """Keep the learning rate and the step count in device memory and let the kernels read them there:
+        a ``step()`` captured in a HIP graph then stays correct on every replay."""
+        if self.dev_lr is None:
+            dev = self.flat_p.device
+            self.dev_lr = torch.full((1,), self._lr, dtype=torch.float32, device=dev)
+            self.dev_step = torch.full((1,), self.step_count, dtype=torch.int64, device=dev)
+
     def zero_grad(self) -> None:
         self.flat_g.zero_()
         for p, gv in zip(self.params, self._gviews):
@@ -91,8 +110,13 @@ class FlatAdam:
         self._gather_stray_grads()
         self.step_count += 1
         B = get_backend()
-        B.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr, self.betas[0],
-                    self.betas[1], self.eps, self.step_count)
+        if self.dev_step is not None:
+            B.counter_add(self.dev_step, 1)
+            B.adam_step_at(self.flat_p, self.flat_g, self.m, self.v, self.dev_lr, self.betas[0], self.betas[1],
+                           self.eps, self.dev_step)
+        else:
+            B.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr, self.betas[0],
+                        self.betas[1], self.eps, self.step_count)
         if hasattr(B, "weights_changed"):
             B.weights_changed(self.flat_p.device)
 

@@ -21,21 +21,36 @@ from .backend import get_backend
 class DeviceRng:
     """Philox-4x32-10 on the device; call ``i`` of rank ``r`` uses stream id (r << 40) | i."""
 
+    EPOCH_STRIDE = 1 << 20      # stream ids of epoch e start at e * 2^20 (SIV_EPOCH_STRIDE of the kernels)
+
     def __init__(self, seed: int = 0, rank: int = 0):
         self.seed = int(seed)
         self.rank = int(rank)
         self.calls = 0
+        self.epoch = None       # device int64 counter, present once use_device_epoch() was called
 
     def _sid(self) -> int:
         sid = (self.rank << 40) | self.calls
         self.calls += 1
         return sid
 
+    def use_device_epoch(self, device) -> torch.Tensor:
+        """From now on every draw adds ``epoch * 2^20`` to its stream id, ``epoch`` being a counter in
+        device memory read when the kernel runs: draws captured in a HIP graph then differ from replay to
+        replay (``advance_epoch`` inside the captured sequence)."""
+        if self.epoch is None:
+            self.epoch = torch.zeros(1, dtype=torch.int64, device=device)
+        return self.epoch
+
+    def advance_epoch(self) -> None:
+        if self.epoch is not None:
+            get_backend().counter_add(self.epoch, 1)
+
     def keep_mask(self, shape, p: float, device) -> torch.Tensor:
-        return get_backend().dropout_keep(shape, device, p, self.seed, self._sid())
+        return get_backend().dropout_keep(shape, device, p, self.seed, self._sid(), self.epoch)
 
     def eps(self, shape, device) -> torch.Tensor:
-        return get_backend().randn(shape, device, self.seed, self._sid())
+        return get_backend().randn(shape, device, self.seed, self._sid(), self.epoch)
 
 
 class ReplayRng:

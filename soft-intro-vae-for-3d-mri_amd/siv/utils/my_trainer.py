@@ -166,6 +166,74 @@ class SoftIntroStep:
             torch.stack([stats_e[0], lossD.detach(), stats_e[1], fake_kl, rec_kl, loss_rec, stats_e[2], stats_e[3]]))
 
 
+class GraphedSoftIntroStep:
+    """One ``SoftIntroStep`` iteration captured in a HIP graph and replayed.
+
+    An iteration is ~1300 kernel launches; issued one by one from Python they cost ~60 ms of host time,
+    which bounds small batches and the narrow FC-latent model.  Captured once (all forward passes, both
+    backward passes, both Adam updates) and replayed, the host cost is one graph launch.  What has to
+    change from step to step lives in device memory: the inputs (copied into static buffers), the random
+    stream (``DeviceRng`` epoch counter, advanced inside the graph), Adam's step count and learning rate
+    (``FlatAdam.use_device_state``).  Requires the device generator, fixed batch shapes and a single
+    rank (the RCCL exchange is not captured).  The model, optimiser and generator state are left exactly
+    as they were before the capture (its warm-up iterations are undone)."""
+
+    def __init__(self, step: SoftIntroStep, real_shape, noise_shape, device, warmup: int = 2):
+        r = rng.get_rng()
+        if not isinstance(r, rng.DeviceRng):
+            raise ValueError("graph capture needs the device random generator (siv.rng.DeviceRng)")
+        if step.sync.collective:
+            raise ValueError("graph capture is single-rank: the gradient exchange is not captured")
+        self.step, self.rng = step, r
+        device = torch.device(device)
+        r.use_device_epoch(device)
+        step.opt_e.use_device_state()
+        step.opt_d.use_device_state()
+        self.real = torch.rand(tuple(real_shape), device=device)
+        self.noise = torch.randn(tuple(noise_shape), device=device)
+        model, opts = step.model, (step.opt_e, step.opt_d)
+        saved_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        saved_opt = [(o.m.clone(), o.v.clone(), o.step_count) for o in opts]
+        saved_calls = r.calls
+        cur = torch.cuda.current_stream(device)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                     # warm-up off the default stream: lazy allocations
+            for _ in range(warmup):
+                step(self.real, self.noise)
+        cur.wait_stream(side)
+        self.sid_base = r.calls                           # stream ids baked into the graph start here
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = step(self.real, self.noise)
+            r.advance_epoch()
+        # undo warm-up and capture: nothing was trained yet
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(saved_sd[k])
+            for o, (m, v, n) in zip(opts, saved_opt):
+                o.m.copy_(m)
+                o.v.copy_(v)
+                o.step_count = n
+                o.dev_step.fill_(n)
+            r.epoch.zero_()
+        r.calls = saved_calls
+        self.replays = 0
+
+    def __call__(self, real_batch, noise_batch):
+        self.real.copy_(real_batch)
+        self.noise.copy_(noise_batch)
+        self.graph.replay()
+        self.replays += 1
+        for o in (self.step.opt_e, self.step.opt_d):
+            o.step_count += 1
+        from ..backend import get_backend
+        B = get_backend()
+        if hasattr(B, "weights_changed"):                 # the replay updated the weights behind the host's back
+            B.weights_changed(self.real.device)
+        return self.out
+
+
 STAT_NAMES = ("lossE", "lossD", "kl_real", "fake_kl", "rec_kl", "loss_rec", "exp_elbo_rec", "exp_elbo_fake")
 
 

@@ -601,3 +601,53 @@ def test_fc_z600_benchmark_model_step():
             assert float(gr.abs().max()) == 0.0, k
         elif not cancelled:
             np.testing.assert_allclose(float(gr.norm()), float(rg.norm()), rtol=2e-2, err_msg=k)
+
+
+def test_graphed_step_matches_eager_step():
+    """The iteration captured in a HIP graph and replayed twice against the same two iterations launched
+    kernel by kernel (same weights, same inputs, same random stream ids incl. the per-replay epoch): loss
+    statistics, weights after each iteration (both Adam step counts live in device memory), BatchNorm
+    running statistics.  Also: the capture leaves model, optimiser and generator untouched."""
+    import siv.models.models as models
+    import siv.rng as srng
+    import siv.utils.my_trainer as trainer
+    from siv.optim import FlatAdam
+    dims, Bn = (16, 24, 16), 2
+    gen = torch.Generator().manual_seed(51)
+    batches = [(torch.rand(Bn, 1, *dims, generator=gen).cuda(), torch.randn(Bn, 1, 4, 6, 4, generator=gen).cuda())
+               for _ in range(2)]
+
+    def build():
+        torch.manual_seed(50)
+        net = models.SoftIntroVAE(*WIDE)
+        net.apply(trainer.init_weights_he)
+        net = net.to("cuda").train()
+        oe, od = FlatAdam(net.encoder.parameters(), lr=2e-4), FlatAdam(net.decoder.parameters(), lr=2e-4)
+        return net, oe, od, trainer.SoftIntroStep(net, oe, od)
+
+    srng.manual_seed(9, 0)
+    net_g, oe_g, od_g, step_g = build()
+    sd_before = {k: v.detach().clone() for k, v in net_g.state_dict().items()}
+    g = trainer.GraphedSoftIntroStep(step_g, batches[0][0].shape, batches[0][1].shape, "cuda")
+    for k, v in net_g.state_dict().items():
+        assert torch.equal(v, sd_before[k]), "capture changed " + k
+    assert oe_g.step_count == 0 and int(oe_g.dev_step) == 0 and srng.get_rng().calls == 0
+    out_g, sd_g = [], []
+    for real, noise in batches:
+        out_g.append(g(real, noise).clone())
+        sd_g.append({k: v.detach().clone() for k, v in net_g.state_dict().items()})
+    assert oe_g.step_count == 2 and int(oe_g.dev_step) == 2 and int(srng.get_rng().epoch) == 2
+
+    net_e, oe_e, od_e, step_e = build()
+    r = srng.DeviceRng(9, 0)
+    srng.set_rng(r)
+    for i, (real, noise) in enumerate(batches):
+        r.calls = g.sid_base + i * srng.DeviceRng.EPOCH_STRIDE          # the ids the graph uses in replay i
+        out = step_e(real, noise)
+        np.testing.assert_allclose(out_g[i].cpu().numpy(), out.cpu().numpy(), rtol=1e-6, err_msg=f"stats of step {i}")
+        for k, v in net_e.state_dict().items():
+            if v.is_floating_point():
+                np.testing.assert_allclose(sd_g[i][k].cpu().numpy(), v.detach().cpu().numpy(), rtol=1e-6, atol=1e-7,
+                                           err_msg=f"step {i}: {k}")
+            else:
+                assert int(sd_g[i][k]) == int(v), k
