@@ -11,6 +11,7 @@
 
 namespace siv {
 
+constexpr int THIN_CUS = 256;                         // MI355X
 constexpr int TB_D = 4, TB_H = 8, TB_W = 8;           // output brick
 constexpr int TH_D = 6, TH_H = 10, TH_W = 10;         // halo brick
 constexpr int TB_V = TB_D * TB_H * TB_W;              // 256
@@ -91,6 +92,84 @@ __global__ __launch_bounds__(256) void one_to_c_k(const float* __restrict__ a,
                 acc.w = fmaf(av, wr[t].w, acc.w);
             }
             *reinterpret_cast<float4*>(out + ((((long)n * D + gz) * H + gy) * W + gx) * C + 4 * q) = acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// one_to_c on the matrix pipe (C <= 64): out = im2col(a) · Wk^T, rows = voxels, K = the 27 taps padded
+// to 28 = seven steps of v_mfma_f32_16x16x4_f32.  Four instructions per step: instruction j owns
+// the channels 4 q + j as its 16 columns, so that a lane (column q) ends up with the four consecutive
+// channels 4 q .. 4 q + 3 of a voxel and the 16 lanes of a row group write one voxel's 256 bytes as one
+// contiguous run.  The weights are the B operands and stay in registers (lane (q, kk): channel
+// 4 q + j, tap 4 s + kk); the A operand of a step is the halo value under tap 4 s + kk of voxel
+// (lane & 15): seven LDS reads feed the 28 instructions of a 16-voxel tile.  Wave wv owns plane wv of
+// every 4x8x8 brick.  The VALU kernel above issues 27 LDS reads and 108 multiply-adds per float4 of
+// output.
+// ---------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 4) void one_to_c_mfma_k(const float* __restrict__ a,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ bias,
+                                                          float* __restrict__ out, int N, int D, int H,
+                                                          int W, int C, int flip, int nbd, int nbh, int nbw,
+                                                          int bricks_per_block, int nbricks) {
+    __shared__ float hal[2][TH_V];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = lane & 15, kk = lane >> 4;
+    const bool qok = 4 * q < C;
+    float wb[7][4];
+    int toff[7];
+#pragma unroll
+    for (int st = 0; st < 7; ++st) {
+        const int t = 4 * st + kk;
+        toff[st] = t < 27 ? ((t / 9) * TH_H + (t / 3) % 3) * TH_W + t % 3 : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * q + j;
+            wb[st][j] = (t < 27 && qok) ? (flip ? w[(26 - t) * C + c] : w[c * 27 + t]) : 0.f;
+        }
+    }
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && qok) b4 = *reinterpret_cast<const float4*>(bias + 4 * q);
+    const int b0 = blockIdx.x * bricks_per_block;
+    const int b1 = b0 + bricks_per_block < nbricks ? b0 + bricks_per_block : nbricks;
+    int buf = 0;
+    for (int br = b0; br < b1; ++br, buf ^= 1) {
+        int n, z0, y0, x0;
+        brick_coords(br, nbd, nbh, nbw, n, z0, y0, x0);
+        // two halo images: a wave still working on the previous brick reads the other one
+        load_halo1(a, hal[buf], n, z0, y0, x0, D, H, W);
+        __syncthreads();
+        const int gz = z0 + wv;
+        if (gz >= D) continue;
+        float* op = out + ((((long)n * D + gz) * H + y0) * W + x0) * C + 4 * q;
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {                // 16 voxels = brick rows 2 tl, 2 tl + 1
+            const float* hp = hal[buf] + (wv * TH_H + 2 * tl + (q >> 3)) * TH_W + (q & 7);
+            float av[7];
+#pragma unroll
+            for (int st = 0; st < 7; ++st) av[st] = hp[toff[st]];
+            f32x4 acc[4];
+            acc[0] = f32x4{b4.x, b4.x, b4.x, b4.x};
+            acc[1] = f32x4{b4.y, b4.y, b4.y, b4.y};
+            acc[2] = f32x4{b4.z, b4.z, b4.z, b4.z};
+            acc[3] = f32x4{b4.w, b4.w, b4.w, b4.w};
+#pragma unroll
+            for (int st = 0; st < 7; ++st)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], wb[st][j], acc[j], 0, 0, 0);
+            // register e of every accumulator belongs to voxel 4 kk + e of the tile
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = 4 * kk + e;
+                const int dy = 2 * tl + (m >> 3), dx = m & 7;
+                if (qok && y0 + dy < H && x0 + dx < W)
+                    *reinterpret_cast<float4*>(op + ((long)dy * W + dx) * C) =
+                        make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
+            }
         }
     }
 }
@@ -390,6 +469,135 @@ __global__ __launch_bounds__(256) void c_to_one_zwalk_k(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------
+// The column walk with 12 x 16 columns: the 14 x 18 halo plane is 252 voxels = eight full row tiles, two
+// per wave (the 8 x 16 column has six: two SIMDs carry two tiles, two carry one), and 1.31x the tensor
+// is read.  Only the tap image of the CURRENT plane is kept (two copies, written alternately, so one
+// barrier per plane suffices): the gather thread of an output voxel adds the nine taps of each kd
+// from it and carries the sums for output planes z and z + 1 in registers; output plane z - 1 is
+// complete when input plane z has been gathered.  The loads of plane z + 1 are issued before the
+// products of plane z, so they have the whole GEMM phase to arrive.
+// ---------------------------------------------------------------------------------
+constexpr int ZX_H = 12, ZX_W = 16, ZX_HW = ZX_W + 2, ZX_HV = (ZX_H + 2) * ZX_HW;   // 252 halo voxels
+constexpr int ZX_TILES = (ZX_HV + 31) / 32;                                          // 8
+
+template <int KG>
+__global__ __launch_bounds__(256, 2) void c_to_one_zwalk12_k(const float* __restrict__ a,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ out, int N, int D, int H,
+                                                             int W, int flip, int nth, int ntw, int zsplit) {
+    constexpr int C = 8 * KG;
+    static_assert(ZX_TILES == 8, "two row tiles per wave");
+    __shared__ float pim[2][ZX_TILES * 32 * C1_PP];    // all 256 rows of the eight tiles are written
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    float4 bw[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < 27) {
+            const int c = 8 * g + 4 * h;
+            if (!flip) {
+                v = *reinterpret_cast<const float4*>(w + i * C + c);
+            } else {
+                v = make_float4(w[(c + 0) * 27 + 26 - i], w[(c + 1) * 27 + 26 - i],
+                                w[(c + 2) * 27 + 26 - i], w[(c + 3) * 27 + 26 - i]);
+            }
+        }
+        bw[g] = v;
+    }
+    int b = blockIdx.x;
+    const int zp = b % zsplit; b /= zsplit;
+    const int tx = b % ntw; b /= ntw;
+    const int ty = b % nth;
+    const int n = b / nth;
+    const int zlo = (int)((long)zp * D / zsplit), zhi = (int)((long)(zp + 1) * D / zsplit);
+    const int y0 = ty * ZX_H, x0 = tx * ZX_W;
+
+    int off[2];
+    bool okv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int u = (wv + 4 * q) * 32 + i;
+        const int hy = u / ZX_HW, hx = u % ZX_HW;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        okv[q] = u < ZX_HV && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        off[q] = okv[q] ? (gy * W + gx) * C + 4 * h : 0;
+    }
+    const float* an = a + (long)n * D * H * W * C;
+    float4 av[2][2][KG];
+    auto load_plane = [&](float4 (&dst)[2][KG], int z) {
+        const bool zok = z >= 0 && z < D;
+        const float* pl = an + (long)(zok ? z : 0) * H * W * C;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int g = 0; g < KG; ++g)   // always a valid address (offset 0 / plane 0 when masked):
+                dst[q][g] = *reinterpret_cast<const float4*>(pl + off[q] + 8 * g);   // masked at use
+    };
+    const float b0 = bias ? bias[0] : 0.f;
+    const int m = threadIdx.x;
+    const int dy = m >> 4, dx = m & 15;                 // gather: threads 0..191
+    const bool gok = m < ZX_H * ZX_W && y0 + dy < H && x0 + dx < W;
+    float* op = out + (long)n * D * H * W + (long)(y0 + dy) * W + x0 + dx;
+    float o_z = b0, o_z1 = b0;                          // running sums of output planes z - 1 and z
+
+    // Planes zlo - 1 .. zhi, two per trip with nothing conditional in between (a branch around the
+    // loads would make the compiler wait for them at the join): an odd count runs one plane more,
+    // whose output plane is outside the range and not stored; loads beyond the volume read plane 0.
+    load_plane(av[0], zlo - 1);
+    for (int zz = zlo - 1; zz <= zhi; zz += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int z = zz + par;
+            load_plane(av[par ^ 1], z + 1);
+            __builtin_amdgcn_sched_barrier(0);          // keep the loads ahead of the products
+            float* pz = pim[par];
+            f32x16 acc[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+            const bool zin = z >= 0 && z < D;
+            const bool ok0 = zin && okv[0], ok1 = zin && okv[1];
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {              // the two row tiles alternate: independent chains
+                const float4 v0 = av[par][0][g], v1 = av[par][1][g];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok0 ? v0.x : 0.f, bw[g].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok1 ? v1.x : 0.f, bw[g].x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok0 ? v0.y : 0.f, bw[g].y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok1 ? v1.y : 0.f, bw[g].y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok0 ? v0.z : 0.f, bw[g].z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok1 ? v1.z : 0.f, bw[g].z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok0 ? v0.w : 0.f, bw[g].w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok1 ? v1.w : 0.f, bw[g].w, acc[1], 0, 0, 0);
+            }
+            if (i < 27) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int u = (wv + 4 * q) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        pz[u * C1_PP + i] = acc[q][r];
+                    }
+            }
+            __syncthreads();
+            if (gok) {
+                float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 27; ++t)
+                    s[t / 9] += pz[((dy + (t / 3) % 3) * ZX_HW + dx + t % 3) * C1_PP + t];
+                // input plane z is under tap kd of output plane z + 1 - kd
+                const float done = o_z + s[2];
+                if (z - 1 >= zlo && z - 1 < zhi) op[(long)(z - 1) * H * W] = done;
+                o_z = o_z1 + s[1];
+                o_z1 = b0 + s[0];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // thin_wg.  Thread = (voxel lane, channel quad) with 27 (+1 for the plain sum of g) float4
 // accumulators; every block walks a contiguous range of bricks, then the voxel lanes are
 // combined through LDS and one partial row per block is written: part[block][C][28].
@@ -454,6 +662,122 @@ __global__ __launch_bounds__(256) void thin_wg_k(const float* __restrict__ a,
     }
 }
 
+// ---------------------------------------------------------------------------------
+// thin_wg on the matrix pipe (C <= 64).  T = G^T · im2col(a): rows = channels, columns = the 27 taps
+// plus a column of ones (the plain sum of g), K = voxels, four per v_mfma_f32_16x16x4_f32.
+// Wave wv owns plane wv of every 4x8x8 brick of the block and walks it in groups of four voxels
+// along x: lane (q, kk) loads the channel quad q of voxel kk as one float4 -- a load instruction
+// covers 1 KB of contiguous memory -- and its four components are the A operands of four
+// instructions whose row m stands for channel 4m + j; the B operand is the halo value under tap
+// q (+16) of voxel kk, one LDS read per tap half.  The VALU kernel above needs 27 LDS reads and
+// 108 multiply-adds per float4 of g and is bound by them; here four voxels x 64 channels cost
+// eight 32-cycle matrix instructions.  The four waves are combined through LDS in fixed order and
+// one partial row per block is written, part[block][C][28], as above.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void thin_wg_mfma_k(const float* __restrict__ a,
+                                                      const float* __restrict__ g,
+                                                      float* __restrict__ part, int N, int D, int H, int W,
+                                                      int C, int nbd, int nbh, int nbw,
+                                                      int bricks_per_block) {
+    __shared__ float hal[2][TH_V];
+    __shared__ float red[64 * 28];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = lane & 15, kk = lane >> 4;
+    const bool qok = 4 * q < C;
+    // tap columns q and q + 16 of this lane: halo offset, or the constant column
+    int toff[2];
+    float bconst[2];
+    bool btap[2];
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg) {
+        const int t = q + 16 * cg;
+        btap[cg] = t < 27;
+        toff[cg] = btap[cg] ? ((t / 9) * TH_H + (t / 3) % 3) * TH_W + t % 3 : 0;
+        bconst[cg] = t == 27 ? 1.f : 0.f;
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) acc[j][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long nbricks = (long)N * nbd * nbh * nbw;
+    const long b0 = (long)blockIdx.x * bricks_per_block;
+    long b1 = b0 + bricks_per_block;
+    if (b1 > nbricks) b1 = nbricks;
+    int buf = 0;
+    for (long br = b0; br < b1; ++br, buf ^= 1) {
+        int n, z0, y0, x0;
+        brick_coords((int)br, nbd, nbh, nbw, n, z0, y0, x0);
+        // two halo images: a wave still multiplying the previous brick reads the other one
+        load_halo1(a, hal[buf], n, z0, y0, x0, D, H, W);
+        __syncthreads();
+        const int gz = z0 + wv;
+        if (gz >= D) continue;
+        const float* gp = g + ((((long)n * D + gz) * H + y0) * W + x0) * C + 4 * q;
+        const float* hp = hal[buf] + wv * TH_H * TH_W + kk;
+        // group u (0..15): brick row u >> 1, voxels 4 (u & 1) + kk
+        auto load4 = [&](float4 (&dst)[4], int c4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int dy = 2 * c4 + (u >> 1), dx = 4 * (u & 1) + kk;
+                const bool ok = qok && y0 + dy < H && x0 + dx < W;
+                // masked lanes read the start of the tensor (no branch around the load) and are
+                // zeroed where the value is used, so nothing waits for the load here
+                dst[u] = *reinterpret_cast<const float4*>(ok ? gp + (dy * W + dx) * C : g);
+            }
+        };
+        float4 av[2][4];
+        load4(av[0], 0);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            if (c4 < 3) load4(av[(c4 + 1) & 1], c4 + 1);
+            __builtin_amdgcn_sched_barrier(0);          // keep the loads ahead of the products
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int dy = 2 * c4 + (u >> 1), dx0 = 4 * (u & 1);
+                float bv[2];
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg)
+                    bv[cg] = btap[cg] ? hp[dy * TH_W + dx0 + toff[cg]] : bconst[cg];
+                const bool ok = qok && y0 + dy < H && x0 + dx0 + kk < W;
+                float4 v = av[c4 & 1][u];
+                v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg) {
+                    acc[0][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, bv[cg], acc[0][cg], 0, 0, 0);
+                    acc[1][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, bv[cg], acc[1][cg], 0, 0, 0);
+                    acc[2][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, bv[cg], acc[2][cg], 0, 0, 0);
+                    acc[3][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, bv[cg], acc[3][cg], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // combine the four waves in fixed order: wave w adds its tiles into the LDS image in round w.
+    // Lane (q, kk), register e of acc[j][cg] holds channel 4 (4 kk + e) + j under tap q + 16 cg.
+    float* pp = part + (long)blockIdx.x * C * 28;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wv == w) {
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                const int t = q + 16 * cg;
+                if (t < 28) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int c = 4 * (4 * kk + e) + j;
+                            red[c * 28 + t] = w == 0 ? acc[j][cg][e] : red[c * 28 + t] + acc[j][cg][e];
+                        }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < C * 28; idx += 256) pp[idx] = red[idx];
+}
+
 // mode 0 (stem): dw[c*27+tap] = T[c][tap], dbias[c] = T[c][27]
 // mode 1 (tail): dw[(26-tap)*C+c] = T[c][tap]
 // One wave per output element: lanes stride over the per-block partials, fixed-order wave sum.
@@ -513,6 +837,14 @@ int k3_thin_fwd_launch(const float* a, const float* w, const float* bias, float*
     if (bpb < 1) bpb = 1;
     if (bpb > 8) bpb = 8;
     const int nbr = (int)nblk;
+    if (Ca == 1 && Cb <= 64) {
+        // four bricks per block measured best (2, 8: +3 %; one round of 19-brick blocks: +12 %)
+        bpb = (int)cdiv(nblk, 4096) < 4 ? (int)cdiv(nblk, 4096) : 4;
+        const unsigned grid = (unsigned)cdiv(nblk, bpb);
+        one_to_c_mfma_k<<<grid, 256, 0, s>>>(a, w, bias, out, N, D, H, W, Cb, flip, nbd, nbh, nbw, bpb, nbr);
+        SIV_CHECK_LAUNCH("conv3d_k3(thin, matrix)");
+        return SIV_OK;
+    }
     if (Ca == 1) {
         one_to_c_k<<<(unsigned)cdiv(nblk, bpb), 256, 0, s>>>(a, w, bias, out, N, D, H, W, Cb, flip, nbd, nbh,
                                                              nbw, bpb, nbr);
@@ -522,6 +854,26 @@ int k3_thin_fwd_launch(const float* a, const float* w, const float* bias, float*
     // the matrix-core kernel runs one brick per block: with several, the barrier between the GEMM and
     // the gather phase of a brick serialises what independent blocks otherwise overlap (measured)
     const unsigned grid = (unsigned)nblk;
+    if (Ca == 64 && D >= 16 && H >= 12 && W >= 16 && (long)H * W * Ca < (1L << 30) &&
+        cdiv(H, ZX_H) * ZX_H * 10 <= cdiv(H, ZW_H) * ZW_H * 11) {
+        // 12 x 16 columns unless they pad H by 10 % more than 8 x 16 ones; two blocks per CU
+        const int nth = (H + ZX_H - 1) / ZX_H, ntw = (W + ZX_W - 1) / ZX_W;
+        // z segments: each repeats two planes, and the two blocks of a CU share its matrix pipe --
+        // take the split with the fewest plane steps on the fullest CU
+        int zsplit = 1;
+        long best = -1;
+        for (int zs = 1; zs <= D / 8; ++zs) {
+            const long rounds = cdiv((long)N * nth * ntw * zs, THIN_CUS);
+            const long cost = rounds * (cdiv(D, zs) + 2);
+            if (best < 0 || cost < best) best = cost, zsplit = zs;
+        }
+        const long nb = (long)N * nth * ntw * zsplit;
+        if (nb <= 0x7fffffffL) {
+            c_to_one_zwalk12_k<8><<<(unsigned)nb, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nth, ntw, zsplit);
+            SIV_CHECK_LAUNCH("conv3d_k3(thin, z-walk 12x16)");
+            return SIV_OK;
+        }
+    }
     if (Ca == 64 && D >= 16 && H >= 8 && W >= 16) {
         // long volumes: z-walking columns (less halo traffic); cut along z until ~1000 blocks
         const int nth = (H + ZW_H - 1) / ZW_H, ntw = (W + ZW_W - 1) / ZW_W;
@@ -561,7 +913,9 @@ int k3_thin_wgrad_launch(const float* x, const float* dy, float* dw, float* dbia
         set_error("conv3d_k3_wgrad(thin): unsupported channel count %d", C);
         return SIV_EINVAL;
     }
-    long nblk = nbricks < 1024 ? nbricks : 1024;
+    const bool mfma = C <= 64;
+    const long cap = mfma ? 4 * THIN_CUS : 1024;      // one round of four blocks per CU
+    long nblk = nbricks < cap ? nbricks : cap;
     const int bpb = (int)cdiv(nbricks, nblk);
     nblk = cdiv(nbricks, bpb);
     const size_t part_bytes = align256((size_t)nblk * C * 28 * sizeof(float));
@@ -569,7 +923,10 @@ int k3_thin_wgrad_launch(const float* x, const float* dy, float* dw, float* dbia
     float* part = (float*)ws;
     const float* a = mode == 0 ? x : dy;
     const float* g = mode == 0 ? dy : x;
-    thin_wg_k<<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb);
+    if (mfma)
+        thin_wg_mfma_k<<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb);
+    else
+        thin_wg_k<<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb);
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(thin)");
     thin_wg_reduce<<<(C * 28 + 3) / 4, 256, 0, s>>>(part, (int)nblk, C, mode, dw, dbias, accumulate);
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(thin reduce)");

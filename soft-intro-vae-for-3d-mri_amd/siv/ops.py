@@ -4,6 +4,7 @@ backward passes run is decided by ``requires_grad`` / ``detach`` exactly as in t
 reference trainer)."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -13,10 +14,13 @@ from .backend import get_backend
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
-# Optionally run a layer's weight gradient on a side stream, concurrently with its input gradient
-# (the two are independent, and the deep layers do not fill the chip on their own).  Measured on the
-# z=1200 model: no gain (540 vs 537 ms per iteration), so it is off by default.
-OVERLAP_WGRAD = False
+# Weight gradients that are accumulated straight into an optimiser's flat gradient buffer have no
+# consumer inside the backward pass, so they can run on a side stream for as long as the pass lasts:
+# the matrix-core bound weight gradient of layer L then shares the chip with the HBM-bound
+# BatchNorm backward of layer L-1 (and fills the CUs a small deep-layer launch leaves idle).  The
+# side stream is joined by a callback at the end of the backward pass, i.e. before ``backward()``
+# returns to the caller.
+OVERLAP_WGRAD = os.environ.get("SIV_OVERLAP_WGRAD", "1") != "0"
 # Parameters managed by siv.optim.FlatAdam carry ``_siv_grad_buf``, the view of the optimiser's flat
 # gradient buffer that is their ``.grad``.  The backward passes below then ADD each weight / bias /
 # BatchNorm-affine gradient into that view inside the kernel (``accumulate`` = 1 of the C ABI) and hand
@@ -33,21 +37,31 @@ def _grad_buf(p):
     return buf if (buf is not None and p.grad is buf) else None
 
 
-def _wgrad_beside_dgrad(B, dy, wgrad_fn, dgrad_fn):
-    """Returns (dgrad result, wgrad result); both are safe to use on the current stream."""
+_pending_join = set()
+
+
+def _join_side(device, main):
+    # ``main`` is the stream the backward nodes ran on (the engine's callback may run on another thread)
+    main.wait_stream(get_backend().side_stream(device))
+    _pending_join.discard(device)
+
+
+def _wgrad_on_side_stream(B, x, dy, wgrad_fn):
+    """Launch a weight gradient that accumulates into a flat gradient buffer on the side stream."""
     if not (OVERLAP_WGRAD and dy.is_cuda and hasattr(B, "side_stream")):
-        return dgrad_fn(), wgrad_fn()
-    main = torch.cuda.current_stream(dy.device)
-    side = B.side_stream(dy.device)
-    side.wait_stream(main)
+        wgrad_fn()
+        return
+    dev = dy.device
+    main = torch.cuda.current_stream(dev)
+    side = B.side_stream(dev)
+    side.wait_stream(main)                       # dy, x and the zeroed gradient buffer are ready
     with torch.cuda.stream(side):
-        gw = wgrad_fn()
-    dx = dgrad_fn()
-    main.wait_stream(side)
-    for t in gw:
-        if t is not None:
-            t.record_stream(main)
-    return dx, gw
+        wgrad_fn()
+    for t in (x, dy):
+        t.record_stream(side)                    # their memory must outlive the side-stream launch
+    if dev not in _pending_join:
+        _pending_join.add(dev)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(dev, main))
 
 
 class _Conv3dK3(Function):
@@ -77,18 +91,15 @@ class _Conv3dK3(Function):
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         want_w = ctx.needs_input_grad[1] or want_b
         direct = ctx.needs_input_grad[1] and ctx.w_buf is not None and (not want_b or ctx.b_buf is not None)
-        wgrad = (lambda: B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b, ctx.w_buf, ctx.b_buf)) if direct else \
-            (lambda: B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b))
-        if ctx.needs_input_grad[0] and want_w:
-            dx, (dw, db) = _wgrad_beside_dgrad(B, dy, wgrad, lambda: B.conv3d_k3_dgrad(dy, w, ctx.ups))
-        elif ctx.needs_input_grad[0]:
-            dx = B.conv3d_k3_dgrad(dy, w, ctx.ups)
-        elif want_w:
-            dw, db = wgrad()
-        if direct or not ctx.needs_input_grad[1]:
-            dw = None
         if direct:
-            db = None
+            _wgrad_on_side_stream(B, x, dy,
+                                  lambda: B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b, ctx.w_buf, ctx.b_buf))
+        if ctx.needs_input_grad[0]:
+            dx = B.conv3d_k3_dgrad(dy, w, ctx.ups)
+        if want_w and not direct:
+            dw, db = B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b)
+            if not ctx.needs_input_grad[1]:
+                dw = None
         return dx, dw, db, None, None
 
 
