@@ -8,6 +8,7 @@ can substitute a checker when exercising the host logic on a machine without a G
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -65,7 +66,9 @@ class HipBackend:
         layer, beside its input gradient) can run concurrently with the main stream."""
         st = self._side.get(device)
         if st is None:
-            st = torch.cuda.Stream(device=device)
+            # lowest priority: its kernels fill what the main stream leaves free
+            prio = int(os.environ.get("SIV_SIDE_PRIORITY", max(torch.cuda.Stream.priority_range())))
+            st = torch.cuda.Stream(device=device, priority=prio)
             self._side[device] = st
         return st
 

@@ -46,15 +46,26 @@ def _join_side(device, main):
     _pending_join.discard(device)
 
 
-def _wgrad_on_side_stream(B, x, dy, wgrad_fn):
-    """Launch a weight gradient that accumulates into a flat gradient buffer on the side stream."""
+def _side_ready(B, dy):
+    """Marks the point on the main stream where ``dy`` (and everything before it) is complete; the
+    side-stream launch waits for this event only, so main-stream work enqueued after it -- the layer's
+    own input gradient -- is ahead of the weight gradient in the hardware queues, not behind it."""
     if not (OVERLAP_WGRAD and dy.is_cuda and hasattr(B, "side_stream")):
+        return None
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dy.device))
+    return ev
+
+
+def _wgrad_on_side_stream(B, x, dy, ready, wgrad_fn):
+    """Launch a weight gradient that accumulates into a flat gradient buffer on the side stream."""
+    if ready is None:
         wgrad_fn()
         return
     dev = dy.device
     main = torch.cuda.current_stream(dev)
     side = B.side_stream(dev)
-    side.wait_stream(main)                       # dy, x and the zeroed gradient buffer are ready
+    side.wait_event(ready)                       # dy, x and the zeroed gradient buffer are ready
     with torch.cuda.stream(side):
         wgrad_fn()
     for t in (x, dy):
@@ -91,11 +102,12 @@ class _Conv3dK3(Function):
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         want_w = ctx.needs_input_grad[1] or want_b
         direct = ctx.needs_input_grad[1] and ctx.w_buf is not None and (not want_b or ctx.b_buf is not None)
-        if direct:
-            _wgrad_on_side_stream(B, x, dy,
-                                  lambda: B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b, ctx.w_buf, ctx.b_buf))
+        ready = _side_ready(B, dy) if direct else None
         if ctx.needs_input_grad[0]:
             dx = B.conv3d_k3_dgrad(dy, w, ctx.ups)
+        if direct:
+            _wgrad_on_side_stream(B, x, dy, ready,
+                                  lambda: B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b, ctx.w_buf, ctx.b_buf))
         if want_w and not direct:
             dw, db = B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b)
             if not ctx.needs_input_grad[1]:
