@@ -156,9 +156,11 @@ int siv_conv1x1_wgrad(const float* x, const float* dy, float* dw, float* dbias,
 /* ---- fully connected layers of the FC-latent model ---------------------------------
  * y[b][o] = bias[o] + sum_k x[b][k] w[o][k]: nn.Linear of models/mymodel.py:125 (encoder
  * head, K = forth_ch*150, O = 2*z) and :151 (decoder stem, K = z, O = forth_ch*150).
- * x is [B][K] row-major in the reference's flatten order (channel-major), w is [O][K]. */
+ * x is [B][K] row-major in the reference's flatten order (channel-major), w is [O][K].
+ * Forward and input gradient split the weight matrix over ~4000 waves (K slabs / output-row slabs)
+ * and reduce the partial sums in fixed order: both need the workspace. */
 int siv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int K, int O,
-                   siv_stream_t stream);
+                   void* ws, size_t ws_bytes, siv_stream_t stream);
 int siv_linear_dgrad(const float* dy, const float* w, float* dx, int B, int K, int O,
                      void* ws, size_t ws_bytes, siv_stream_t stream);
 int siv_linear_wgrad(const float* x, const float* dy, float* dw, float* dbias, int B, int K, int O,

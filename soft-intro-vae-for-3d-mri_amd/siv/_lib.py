@@ -30,7 +30,7 @@ SIGNATURES = {
     "siv_conv1x1_fwd": [_f, _f, _f, _f, _l, _i, _i, _f],
     "siv_conv1x1_dgrad": [_f, _f, _f, _l, _i, _i, _f],
     "siv_conv1x1_wgrad": [_f, _f, _f, _f, _l, _i, _i, _i, _f, _sz, _f],
-    "siv_linear_fwd": [_f, _f, _f, _f, _i, _i, _i, _f],
+    "siv_linear_fwd": [_f, _f, _f, _f, _i, _i, _i, _f, _sz, _f],
     "siv_linear_dgrad": [_f, _f, _f, _i, _i, _i, _f, _sz, _f],
     "siv_linear_wgrad": [_f, _f, _f, _f, _i, _i, _i, _i, _f],
     "siv_add_act_fwd": [_f, _f, _fl, _f, _l, _f],

@@ -299,7 +299,8 @@ class HipBackend:
         O = w.shape[0]
         assert w.shape[1] == K, (tuple(w.shape), K)
         y = torch.empty((B, O), device=x.device, dtype=torch.float32)
-        _lib.check(self.lib.siv_linear_fwd(_p(x), _p(w), _p(bias), _p(y), B, K, O, self._stream(x)),
+        ws, wsb = self._workspace(x)
+        _lib.check(self.lib.siv_linear_fwd(_p(x), _p(w), _p(bias), _p(y), B, K, O, ws, wsb, self._stream(x)),
                    "siv_linear_fwd")
         return y
 

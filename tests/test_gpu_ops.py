@@ -395,10 +395,12 @@ def test_axpby(B):
         B.axpby(0.25, yd, 0.0, yd)
 
 
-@pytest.mark.parametrize("b,k,o", [(2, 1200, 32), (8, 19200, 1200), (8, 600, 19200), (3, 37, 5), (11, 130, 64)])
+@pytest.mark.parametrize("b,k,o", [(2, 1200, 32), (8, 19200, 1200), (8, 600, 19200), (3, 37, 5), (11, 130, 64),
+                                   (17, 68, 21), (4, 19200, 1200), (1, 600, 19200), (5, 4, 3)])
 def test_linear_fwd_dgrad_wgrad(B, b, k, o):
     """nn.Linear of the FC-latent model (models/mymodel.py:125,151) incl. the benchmark shapes
-    (B=8: 19200 -> 1200 and 600 -> 19200), a ragged shape and a batch above one register tile."""
+    (B=8: 19200 -> 1200 and 600 -> 19200), ragged shapes on the VALU kernels (K not a multiple of 4) and on
+    the matrix-pipe kernels (partial column groups, slabs and a batch above one 16-row tile)."""
     gen = torch.Generator().manual_seed(b * 7 + k + o)
     x, w, bias = rnd(gen, b, k), rnd(gen, o, k, scale=k ** -0.5), rnd(gen, o)
     dy = rnd(gen, b, o)
@@ -419,9 +421,9 @@ def test_linear_rejects_bad_arguments(B):
     import siv._lib as L
     x = torch.zeros(2, 8, device="cuda")
     with pytest.raises(L.SivError):
-        L.check(B.lib.siv_linear_fwd(x.data_ptr(), None, None, x.data_ptr(), 2, 8, 4, None), "siv_linear_fwd")
+        L.check(B.lib.siv_linear_fwd(x.data_ptr(), None, None, x.data_ptr(), 2, 8, 4, x.data_ptr(), 16, None), "siv_linear_fwd")
     with pytest.raises(L.SivError):
-        L.check(B.lib.siv_linear_fwd(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 0, 8, 4, None), "siv_linear_fwd")
+        L.check(B.lib.siv_linear_fwd(x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 0, 8, 4, x.data_ptr(), 16, None), "siv_linear_fwd")
     with pytest.raises(L.SivError):      # workspace too small for the split-row partial sums
         L.check(B.lib.siv_linear_dgrad(x.data_ptr(), x.data_ptr(), x.data_ptr(), 2, 8, 4, x.data_ptr(), 16, None),
                 "siv_linear_dgrad")
