@@ -63,6 +63,17 @@ __global__ __launch_bounds__(256) void linear_dgrad_partial(const float* __restr
             if (b0 + j < B) part[((long)blockIdx.y * B + b0 + j) * K + k] = acc[j];
     }
 }
+// many slices, few elements: one wave per element, lanes stride over the slices, fixed-order wave sum
+__global__ __launch_bounds__(256) void linear_dgrad_reduce_w(const float* __restrict__ part, int nslice,
+                                                             long n, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    float s = 0.f;
+    for (int t = lane; t < nslice; t += 64) s += part[(long)t * n + i];
+    s = wave_sum(s);
+    if (lane == 0) dx[i] = s;
+}
 __global__ __launch_bounds__(256) void linear_dgrad_reduce(const float* __restrict__ part, int nslice,
                                                            long n, float* __restrict__ dx) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -323,7 +334,11 @@ extern "C" int siv_linear_dgrad(const float* dy, const float* w, float* dx, int 
                                                                       slab);
             SIV_CHECK_LAUNCH("linear_dgrad(matrix)");
         }
-        linear_dgrad_reduce<<<lin_grid((long)B * K), 256, 0, s>>>((const float*)ws, nslab, (long)B * K, dx);
+        const long n = (long)B * K;
+        if (nslab >= 64 && n <= 65536)
+            linear_dgrad_reduce_w<<<(unsigned)cdiv(n, 4), 256, 0, s>>>((const float*)ws, nslab, n, dx);
+        else
+            linear_dgrad_reduce<<<lin_grid(n), 256, 0, s>>>((const float*)ws, nslab, n, dx);
         SIV_CHECK_LAUNCH("linear_dgrad(reduce)");
         return SIV_OK;
     }

@@ -651,3 +651,45 @@ def test_graphed_step_matches_eager_step():
                                            err_msg=f"step {i}: {k}")
             else:
                 assert int(sd_g[i][k]) == int(v), k
+
+
+def test_side_stream_weight_gradients_match_serial_backward():
+    """Weight gradients that accumulate into the optimiser's flat buffers run on a side stream that is joined
+    when backward() ends (siv.ops.OVERLAP_WGRAD).  Two iterations with and without it from the same state:
+    every kernel is deterministic and each buffer element is still written by the same launches in the same
+    order (all weight gradients share the one side stream), so statistics, gradients and weights are
+    bit-identical -- and the gradient buffer is complete the moment backward() returns."""
+    import siv.models.models as models
+    import siv.ops as ops
+    import siv.rng as srng
+    import siv.utils.my_trainer as trainer
+    from siv.optim import FlatAdam
+    dims, Bn = (16, 24, 16), 2
+    gen = torch.Generator().manual_seed(61)
+    batches = [(torch.rand(Bn, 1, *dims, generator=gen).cuda(), torch.randn(Bn, 1, 4, 6, 4, generator=gen).cuda())
+               for _ in range(2)]
+    results = []
+    saved = ops.OVERLAP_WGRAD
+    try:
+        for overlap in (True, False):
+            ops.OVERLAP_WGRAD = overlap
+            torch.manual_seed(60)
+            net = models.SoftIntroVAE(*WIDE)
+            net.apply(trainer.init_weights_he)
+            net = net.to("cuda").train()
+            oe, od = FlatAdam(net.encoder.parameters(), lr=2e-4), FlatAdam(net.decoder.parameters(), lr=2e-4)
+            step = trainer.SoftIntroStep(net, oe, od)
+            srng.set_rng(srng.DeviceRng(13, 0))
+            grads = []
+            e_step, d_step = oe.step, od.step
+            oe.step = lambda: (grads.append(oe.flat_g.clone()), e_step())      # right after lossE.backward()
+            od.step = lambda: (grads.append(od.flat_g.clone()), d_step())
+            stats = [step(real, noise).clone() for real, noise in batches]
+            results.append((stats, grads, oe.flat_p.clone(), od.flat_p.clone()))
+    finally:
+        ops.OVERLAP_WGRAD = saved
+    (s1, g1, pe1, pd1), (s0, g0, pe0, pd0) = results
+    assert len(g1) == len(g0) == 4
+    for a, b in zip(s1 + g1 + [pe1, pd1], s0 + g0 + [pe0, pd0]):
+        assert torch.equal(a, b)
+    assert float(g1[0].abs().max()) > 0 and float(g1[1].abs().max()) > 0
