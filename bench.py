@@ -107,6 +107,60 @@ def cpu_baseline():
                       f"({times[0]:.1f} s), then median of 3 = {t:.2f} s per step"}
 
 
+def fc_config_entry(device, steps=5, warmup=2):
+    """BASELINE configs[1] beside the headline number (not part of it): the FC-latent z=600 model
+    mymodel.SoftIntroVAE(16,32,64,128,600), batch 4, one GPU -- iteration time, and its Linear(19200 -> 1200)
+    forward against the HBM peak (the layer streams its 92 MB weight matrix once; with 4 batch rows on a
+    16-row matrix-core tile the matrix pipe is never the limit: its FLOP rate is reported, not a roofline)."""
+    import siv.backend as sb
+    import siv.models.mymodel as mymodel
+    import siv.rng as srng
+    import siv.utils.my_trainer as trainer
+    from siv.optim import FlatAdam
+    batch = 4
+    torch.manual_seed(82)
+    net = mymodel.SoftIntroVAE(16, 32, 64, 128, 600)
+    torch.manual_seed(77)
+    net.apply(trainer.init_weights_he)
+    net = net.to(device).train()
+    opt_e = FlatAdam(net.encoder.parameters(), lr=2e-4)
+    opt_d = FlatAdam(net.decoder.parameters(), lr=2e-4)
+    step = trainer.SoftIntroStep(net, opt_e, opt_d, 1.0, 1024.0, 0.75, 1e-8, None, None)
+    gen = torch.Generator().manual_seed(103)
+    real = [torch.rand(batch, 1, *DIMS, generator=gen).to(device) for _ in range(2)]
+    for i in range(warmup + steps):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        st = step(real[i % 2], srng.get_rng().eps((batch, net.z_ch), device))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert bool(torch.isfinite(st).all())
+    B = sb.get_backend()
+    K, O = 19200, 1200
+    x = torch.randn(batch, K, device=device)
+    w = torch.randn(O, K, device=device) * K ** -0.5
+    B.linear_fwd(x, w, None)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        B.linear_fwd(x, w, None)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    byts = (O * K + batch * K + batch * O) * 4
+    return {"workload": "BASELINE configs[1]: 80x96x80 fp32, z=600, mymodel.SoftIntroVAE(16,32,64,128,600), batch 4",
+            "ms_per_step": round(dt * 1e3, 2), "volumes_per_s": round(batch / dt, 2), "steps": steps,
+            "linear_19200_to_1200_fwd": {"bound": "hbm", "achieved": round(byts / (ms * 1e-3) / 1e9, 1),
+                                         "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
+                                         "frac": round(byts / (ms * 1e-3) / 1e9 / (HBM_PEAK_TBS * 1e3), 4),
+                                         "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": byts,
+                                         "mfma_tflops_issued": round(2.0 * 16 * K * O / (ms * 1e-3) / 1e12, 2),
+                                         "mfma_frac_of_fp32_peak": round(2.0 * 16 * K * O / (ms * 1e-3) / 1e12
+                                                                         / FP32_PEAK_TFLOPS, 4)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +168,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="volumes per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fc", action="store_true", help="skip the FC-latent z=600 side measurement")
     ap.add_argument("--graph", action="store_true",
                     help="single GPU: capture the iteration in a HIP graph and replay it (the per-kernel "
                          "event timing of the roofline fields is then taken from two eager iterations)")
@@ -337,6 +392,8 @@ def main():
             "split_bf16_products": split,
             "losses": {k: stats[k] for k in ("lossE", "lossD", "loss_rec", "kl_real")},
         }
+        if world == 1 and not args.no_fc:
+            out["fc_config"] = fc_config_entry(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()
