@@ -37,13 +37,12 @@ def _grad_buf(p):
     return buf if (buf is not None and p.grad is buf) else None
 
 
-_pending_join = set()
+_join_queued = {}        # device -> id of the backward pass (autograd graph task) whose end joins the side stream
 
 
 def _join_side(device, main):
     # ``main`` is the stream the backward nodes ran on (the engine's callback may run on another thread)
     main.wait_stream(get_backend().side_stream(device))
-    _pending_join.discard(device)
 
 
 def _side_ready(B, dy):
@@ -70,8 +69,11 @@ def _wgrad_on_side_stream(B, x, dy, ready, wgrad_fn):
         wgrad_fn()
     for t in (x, dy):
         t.record_stream(side)                    # their memory must outlive the side-stream launch
-    if dev not in _pending_join:
-        _pending_join.add(dev)
+    # one join per backward pass, keyed by the pass itself: a pass that died in an exception must not
+    # leave the next one without its join
+    task = torch._C._current_graph_task_id()
+    if _join_queued.get(dev) != task:
+        _join_queued[dev] = task
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(dev, main))
 
 
