@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Sanity run of the training path on the device: the z=1200 model, batch 8, a fixed pool of synthetic
+volumes with structure (smooth blobs), a few dozen iterations.  Prints the statistics every few
+iterations and a checksum of the final weights (the run is deterministic: two runs, or a run with
+SIV_OVERLAP_WGRAD=0, must print the same line); nothing may become non-finite.  (The reconstruction term
+has a high floor by construction -- the model ends in Dropout(0.35) -- and the adversarial objective makes
+the first hundred iterations jumpy; this is a smoke test of the machinery, not of convergence.)"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "soft-intro-vae-for-3d-mri_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+
+def main():
+    import siv.models.models as models
+    import siv.rng as srng
+    import siv.utils.my_trainer as trainer
+    from siv.optim import FlatAdam
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    dev = torch.device("cuda")
+    torch.manual_seed(82)
+    net = models.soft_intro_vae_z1200()
+    torch.manual_seed(77)
+    net.apply(trainer.init_weights_he)
+    net = net.to(dev).train()
+    opt_e = FlatAdam(net.encoder.parameters(), lr=2e-4)
+    opt_d = FlatAdam(net.decoder.parameters(), lr=2e-4)
+    step = trainer.SoftIntroStep(net, opt_e, opt_d)
+    srng.manual_seed(77, 0)
+    gen = torch.Generator().manual_seed(3)
+    # smooth synthetic "anatomy": low-resolution noise upsampled, squashed into [0, 1]
+    low = torch.rand(16, 1, 10, 12, 10, generator=gen)
+    pool = torch.nn.functional.interpolate(low, size=(80, 96, 80), mode="trilinear", align_corners=False)
+    pool = ((pool - pool.amin()) / (pool.amax() - pool.amin())).to(dev)
+    hist = []
+    for it in range(iters):
+        real = pool[(it % 2) * 8:(it % 2) * 8 + 8]
+        noise = srng.get_rng().eps((8, 1, 10, 12, 10), dev)
+        st = dict(zip(trainer.STAT_NAMES, step(real, noise).cpu().tolist()))
+        assert all(v == v and abs(v) != float("inf") for v in st.values()), (it, st)
+        if it % 10 == 0 or it == iters - 1:
+            hist.append((it, round(st["loss_rec"], 1), round(st["kl_real"], 1), round(st["lossE"], 3), round(st["lossD"], 3)))
+            print(hist[-1], flush=True)
+    first, last = hist[0][1], hist[-1][1]
+    chk = float(opt_e.flat_p.double().sum()) + float(opt_d.flat_p.double().sum())
+    print(json.dumps({"iterations": iters, "loss_rec_first": first, "loss_rec_min": min(h[1] for h in hist),
+                      "loss_rec_last": last, "weights_checksum": repr(chk)}))
+
+
+if __name__ == "__main__":
+    main()
