@@ -8,7 +8,6 @@ can substitute a checker when exercising the host logic on a machine without a G
 """
 from __future__ import annotations
 
-import os
 from typing import Optional, Tuple
 
 import torch
@@ -66,9 +65,8 @@ class HipBackend:
         layer, beside its input gradient) can run concurrently with the main stream."""
         st = self._side.get(device)
         if st is None:
-            # lowest priority: its kernels fill what the main stream leaves free
-            prio = int(os.environ.get("SIV_SIDE_PRIORITY", max(torch.cuda.Stream.priority_range())))
-            st = torch.cuda.Stream(device=device, priority=prio)
+            # default priority: the priority range of this device is (0, -1), there is nothing below it
+            st = torch.cuda.Stream(device=device)
             self._side[device] = st
         return st
 
