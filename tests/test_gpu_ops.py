@@ -64,6 +64,8 @@ CONV_CASES = [
     (32, 1, (8, 12, 8), 1, 1, 0), (24, 1, (6, 7, 5), 2, 1, 0), (1, 32, (5, 9, 8), 2, 1, 0), (1, 24, (6, 7, 5), 1, 1, 0),
     # ... long enough in z for the column-walking 64 -> 1 kernel (forward, and 1 -> 64 input gradient)
     (64, 1, (17, 9, 18), 2, 1, 0), (64, 1, (16, 8, 16), 1, 1, 0), (1, 64, (33, 12, 20), 1, 1, 0),
+    # ... 12 x 16 columns with ragged last tiles in H and W and an odd plane count; 13 rows stay on 8 x 16 columns
+    (64, 1, (19, 44, 36), 2, 1, 0), (64, 1, (16, 13, 16), 1, 1, 0), (1, 64, (24, 24, 32), 3, 1, 0),
     # fp32 matrix-core kernels
     (8, 64, (8, 12, 8), 1, 1, 0), (64, 64, (8, 12, 8), 2, 1, 0), (64, 64, (5, 7, 9), 1, 1, 0),
     (16, 128, (10, 12, 10), 2, 1, 0), (128, 64, (4, 8, 8), 1, 1, 0), (64, 128, (3, 5, 17), 1, 1, 0),
