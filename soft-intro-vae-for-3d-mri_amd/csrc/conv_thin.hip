@@ -114,11 +114,14 @@ __global__ __launch_bounds__(256, 4) void one_to_c_mfma_k(const float* __restric
                                                           const float* __restrict__ bias,
                                                           float* __restrict__ out, int N, int D, int H,
                                                           int W, int C, int flip, int nbd, int nbh, int nbw,
-                                                          int bricks_per_block, int nbricks) {
+                                                          int bricks_per_block, int nbricks,
+                                                          float* __restrict__ stat_part) {
     __shared__ float hal[2][TH_V];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = lane & 15, kk = lane >> 4;
     const bool qok = 4 * q < C;
+    // per-channel sum and sum of squares of the bias-free outputs this lane stores (for a BatchNorm behind)
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
     float wb[7][4];
     int toff[7];
 #pragma unroll
@@ -152,10 +155,8 @@ __global__ __launch_bounds__(256, 4) void one_to_c_mfma_k(const float* __restric
 #pragma unroll
             for (int st = 0; st < 7; ++st) av[st] = hp[toff[st]];
             f32x4 acc[4];
-            acc[0] = f32x4{b4.x, b4.x, b4.x, b4.x};
-            acc[1] = f32x4{b4.y, b4.y, b4.y, b4.y};
-            acc[2] = f32x4{b4.z, b4.z, b4.z, b4.z};
-            acc[3] = f32x4{b4.w, b4.w, b4.w, b4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int st = 0; st < 7; ++st)
 #pragma unroll
@@ -166,10 +167,38 @@ __global__ __launch_bounds__(256, 4) void one_to_c_mfma_k(const float* __restric
             for (int e = 0; e < 4; ++e) {
                 const int m = 4 * kk + e;
                 const int dy = 2 * tl + (m >> 3), dx = m & 7;
-                if (qok && y0 + dy < H && x0 + dx < W)
+                if (qok && y0 + dy < H && x0 + dx < W) {
+                    const float4 v = make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
+                    s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                    s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
+                    s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
                     *reinterpret_cast<float4*>(op + ((long)dy * W + dx) * C) =
-                        make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
+                        make_float4(v.x + b4.x, v.y + b4.y, v.z + b4.z, v.w + b4.w);
+                }
             }
+        }
+    }
+    if (stat_part) {            // part[block][2][C]: the four lanes of a channel quad, then the four waves
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64);
+            s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+            s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64);
+            s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+        }
+        __syncthreads();                       // every wave is done with the halo images
+        float* red = hal[0];                   // [4 waves][2][64 channels]
+        if (lane < 16) {
+            *reinterpret_cast<float4*>(red + (wv * 2 + 0) * 64 + 4 * q) = s1;
+            *reinterpret_cast<float4*>(red + (wv * 2 + 1) * 64 + 4 * q) = s2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int k = threadIdx.x >> 6, c = threadIdx.x & 63;
+            if (c < C)
+                stat_part[((long)blockIdx.x * 2 + k) * C + c] =
+                    (red[(0 * 2 + k) * 64 + c] + red[(1 * 2 + k) * 64 + c]) +
+                    (red[(2 * 2 + k) * 64 + c] + red[(3 * 2 + k) * 64 + c]);
         }
     }
 }
@@ -824,8 +853,23 @@ bool k3_thin_supported(int Cin, int Cout) {
     return false;
 }
 
+// number of blocks (= rows of per-block statistics) of the 1 -> C matrix-pipe kernel, 0 if it does not apply
+static inline void thin_1c_grid(int N, int D, int H, int W, long& nblk, int& bpb) {
+    const int nbd = (D + TB_D - 1) / TB_D, nbh = (H + TB_H - 1) / TB_H, nbw = (W + TB_W - 1) / TB_W;
+    nblk = (long)N * nbd * nbh * nbw;
+    // four bricks per block measured best (2, 8: +3 %; one round of 19-brick blocks: +12 %)
+    bpb = (int)cdiv(nblk, 4096) < 4 ? (int)cdiv(nblk, 4096) : 4;
+}
+long k3_thin_fwd_stat_blocks(int N, int D, int H, int W, int Ca, int Cb) {
+    if (Ca != 1 || Cb > 64) return 0;
+    long nblk;
+    int bpb;
+    thin_1c_grid(N, D, H, W, nblk, bpb);
+    return nblk > 0x7fffffffL ? 0 : cdiv(nblk, bpb);
+}
+
 int k3_thin_fwd_launch(const float* a, const float* w, const float* bias, float* out, int N, int D,
-                       int H, int W, int Ca, int Cb, int flip, hipStream_t s) {
+                       int H, int W, int Ca, int Cb, int flip, hipStream_t s, float* stat_part) {
     const int nbd = (D + TB_D - 1) / TB_D, nbh = (H + TB_H - 1) / TB_H, nbw = (W + TB_W - 1) / TB_W;
     const long nblk = (long)N * nbd * nbh * nbw;
     if (nblk > 0x7fffffffL) {
@@ -838,12 +882,17 @@ int k3_thin_fwd_launch(const float* a, const float* w, const float* bias, float*
     if (bpb > 8) bpb = 8;
     const int nbr = (int)nblk;
     if (Ca == 1 && Cb <= 64) {
-        // four bricks per block measured best (2, 8: +3 %; one round of 19-brick blocks: +12 %)
-        bpb = (int)cdiv(nblk, 4096) < 4 ? (int)cdiv(nblk, 4096) : 4;
+        long nb;
+        thin_1c_grid(N, D, H, W, nb, bpb);
         const unsigned grid = (unsigned)cdiv(nblk, bpb);
-        one_to_c_mfma_k<<<grid, 256, 0, s>>>(a, w, bias, out, N, D, H, W, Cb, flip, nbd, nbh, nbw, bpb, nbr);
+        one_to_c_mfma_k<<<grid, 256, 0, s>>>(a, w, bias, out, N, D, H, W, Cb, flip, nbd, nbh, nbw, bpb, nbr,
+                                             stat_part);
         SIV_CHECK_LAUNCH("conv3d_k3(thin, matrix)");
         return SIV_OK;
+    }
+    if (stat_part) {
+        set_error("conv3d_k3(thin): this kernel emits no statistics");
+        return SIV_EINVAL;
     }
     if (Ca == 1) {
         one_to_c_k<<<(unsigned)cdiv(nblk, bpb), 256, 0, s>>>(a, w, bias, out, N, D, H, W, Cb, flip, nbd, nbh,

@@ -139,8 +139,9 @@ int bn_finalize_launch(const float*, const float*, int, long, int, float*, float
                        int64_t*, float, hipStream_t);
 // conv_thin.hip
 bool k3_thin_supported(int Cin, int Cout);
+long k3_thin_fwd_stat_blocks(int N, int D, int H, int W, int Ca, int Cb);
 int k3_thin_fwd_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int,
-                       int flip, hipStream_t);
+                       int flip, hipStream_t, float* stat_part);
 int k3_thin_wgrad_launch(const float*, const float*, float*, float*, int, int, int, int, int, int,
                          int, void*, size_t, hipStream_t);
 
@@ -273,7 +274,7 @@ extern "C" int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bi
     const int path = conv_path();
     const bool al = aligned16(x) && aligned16(w) && aligned16(y) && aligned16(ws);
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
-        return SIV_PICK("thin"), k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s);
+        return SIV_PICK("thin"), k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s, nullptr);
     if (use_up(path, al, ups, Cin, Cout))
         return SIV_PICK("up"), k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, nullptr, path == 5, path == 6);
     if (use_b3(path, al, ups, Cin, Cout))
@@ -306,10 +307,14 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
     // Kernels whose epilogue emits per-block sums of their bias-free output: the statistics then cost
     // one small finalize launch instead of a pass over y.  The partials sit behind the packed weights.
     const int path = conv_path();
-    enum { NONE, UP, B3, W2D, WINO } fused = NONE;
+    enum { NONE, UP, B3, W2D, WINO, THIN } fused = NONE;
     size_t wbytes = 0;
     long nblk = 0;
-    if (use_up(path, al, ups, Cin, Cout)) {
+    if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout)) {
+        // the single-channel stem: its matrix-pipe kernel sums what it stores; the other thin kernels do not
+        nblk = k3_thin_fwd_stat_blocks(N, D, H, W, Cin, Cout);
+        if (nblk > 0) fused = THIN;
+    } else if (use_up(path, al, ups, Cin, Cout)) {
         fused = UP, wbytes = k2_up_fwd_ws_bytes(Cin, Cout), nblk = k2_up_fwd_blocks(N, D, H, W, path == 5, path == 6);
     } else if (use_b3(path, al, ups, Cin, Cout)) {
         fused = B3, wbytes = k3_fwd_wino_b3_ws_bytes(Cin, Cout), nblk = k3_fwd_wino_bricks(N, D, H, W);
@@ -322,8 +327,9 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
         wbytes = align256(wbytes);
         SIV_CHECK_WS(wbytes + (size_t)nblk * 2 * Cout * sizeof(float), ws_bytes, "conv3d_k3_fwd_bnstats");
         float* part = (float*)((char*)ws + wbytes);
-        SIV_PICK(fused == UP ? "up" : fused == B3 ? "wino_b3" : fused == W2D ? "wino2d" : "wino");
+        SIV_PICK(fused == UP ? "up" : fused == B3 ? "wino_b3" : fused == W2D ? "wino2d" : fused == THIN ? "thin" : "wino");
         switch (fused) {
+        case THIN: rc = k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s, part); break;
         case UP: rc = k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, part, path == 5, path == 6); break;
         case B3: rc = k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part); break;
         case W2D: rc = k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part); break;
@@ -347,7 +353,7 @@ static int dgrad_dispatch(const char* what, const float* dy, const float* w, con
     const int path = conv_path();
     const bool al = aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws);
     if (path != 1 && al && k3_thin_supported(Cout, Cin))
-        return SIV_PICK("thin"), k3_thin_fwd_launch(dy, w, bias, dx, N, D, H, W, Cout, Cin, 1, s);
+        return SIV_PICK("thin"), k3_thin_fwd_launch(dy, w, bias, dx, N, D, H, W, Cout, Cin, 1, s, nullptr);
     if (use_b3(path, al, 1, Cout, Cin))
         return SIV_PICK("wino_b3"), k3_fwd_wino_b3_launch(dy, w, bias, dx, N, D, H, W, Cout, Cin, 1, ws, ws_bytes, s, nullptr);
     if (use_w2d(path, al, 1, N, D, H, W, Cout, Cin))

@@ -454,6 +454,9 @@ def test_add_act(B, shape):
     # ... and the product form of the upsampled kernel (forced by path 6; one-plane bricks, 20-wide variant)
     (64, 128, (8, 8, 16), 1, 2, 6, True), (16, 64, (10, 24, 20), 1, 2, 6, False), (8, 64, (6, 10, 14), 2, 2, 6, True),
     (4, 8, (6, 7, 5), 2, 1, 0, True), (1, 8, (8, 12, 8), 2, 1, 0, True), (64, 64, (10, 12, 10), 1, 1, 0, False),
+    # ... and the single-channel stem on the matrix pipe (ragged bricks, several bricks per block, narrow widths)
+    (1, 64, (9, 10, 11), 2, 1, 0, True), (1, 64, (16, 24, 40), 3, 1, 0, True), (1, 16, (7, 9, 12), 2, 1, 0, False),
+    (1, 12, (6, 7, 5), 1, 1, 0, True),
 ])
 def test_conv_fwd_with_bn_statistics(B, cin, cout, dims, n, ups, path, use_bias):
     """siv_conv3d_k3_fwd_bnstats == convolution followed by siv_bn_stats (incl. running statistics),
