@@ -121,6 +121,25 @@ int siv_conv3d_k3_dgrad_up(const float* dy, const float* w, float* dx, int N, in
 int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, float* dbias,
                         int N, int D, int H, int W, int Cin, int Cout, int ups, int accumulate,
                         void* ws, size_t ws_bytes, siv_stream_t stream);
+/* BatchNorm3d + LeakyReLU folded into the Cin -> 1 convolution behind them: the decoder's last block
+ * ends in conv -> BatchNorm -> LeakyReLU and feeds the output layer nn.Conv3d(in_ch, 1, 3, 1, 1)
+ * (models/models.py:76-78 and :137).  x is the block's RAW convolution output [N][D][H][W][Cin]; the
+ * kernels apply z = x*a + b (a = gamma/sqrt(var+eps), b = beta - mean*a), LeakyReLU(slope) and the zero
+ * padding of the activated tensor while they load x, so the activated full-resolution tensor is never
+ * written or read.  _fwd: y[N][D][H][W] = conv(act(bn(x)), w[1][27][Cin]) + bias.  _wgrad: dw[1][27][Cin]
+ * (+ dbias[1]) from dy[N][D][H][W] and the same x.  The gradient with respect to the activation is the
+ * plain siv_conv3d_k3_dgrad of dy; BatchNorm's own backward (siv_bn_act_bwd) takes it from there.
+ * _supported: 1 when _fwd has a kernel for the shape (64 channels, D >= 16, H >= 12, W >= 16). */
+int siv_bnact_conv3d_k3_to1_supported(int N, int D, int H, int W, int Cin);
+int siv_bnact_conv3d_k3_to1_fwd(const float* x, const float* mean, const float* var, const float* gamma,
+                                const float* beta, float eps, float slope, const float* w,
+                                const float* bias, float* y, int N, int D, int H, int W, int Cin,
+                                siv_stream_t stream);
+int siv_bnact_conv3d_k3_to1_wgrad(const float* x, const float* mean, const float* var, const float* gamma,
+                                  const float* beta, float eps, float slope, const float* dy, float* dw,
+                                  float* dbias, int N, int D, int H, int W, int Cin, int accumulate,
+                                  void* ws, size_t ws_bytes, siv_stream_t stream);
+
 /* Backward of nn.Upsample(scale_factor=2, nearest): dx[n][d][h][w][c] = sum of the
  * 2x2x2 children of dy.  D,H,W are the extents of dy (even). */
 int siv_upsample2_bwd(const float* dy, float* dx, int N, int D, int H, int W, int C,

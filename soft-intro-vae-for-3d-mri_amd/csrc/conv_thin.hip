@@ -509,15 +509,36 @@ __global__ __launch_bounds__(256) void c_to_one_zwalk_k(const float* __restrict_
 constexpr int ZX_H = 12, ZX_W = 16, ZX_HW = ZX_W + 2, ZX_HV = (ZX_H + 2) * ZX_HW;   // 252 halo voxels
 constexpr int ZX_TILES = (ZX_HV + 31) / 32;                                          // 8
 
-template <int KG>
+// BatchNorm of the layer in front, for the kernels that apply it (and the LeakyReLU behind it) to their
+// operand instead of reading an activated tensor: z = x * a[c] + b[c] with a = gamma / sqrt(var + eps),
+// b = beta - mean * a (the arithmetic of bn_act_fwd_k), act(z) = z > 0 ? z : z * slope.
+__device__ __forceinline__ void bn_coeff(const BnPrologue& bn, int c, float& a, float& b) {
+    a = bn.gamma[c] / sqrtf(bn.var[c] + bn.eps);
+    b = bn.beta[c] - bn.mean[c] * a;
+}
+__device__ __forceinline__ float bn_act1(float x, float a, float b, float slope) {
+    const float z = fmaf(x, a, b);
+    return z > 0.f ? z : z * slope;
+}
+
+// BN: the operand a is the raw output of the convolution in front; BatchNorm + LeakyReLU are applied to
+// every loaded value (coefficients in LDS), out-of-volume voxels stay zero (the padding of the ACTIVATED
+// tensor).  The activated tensor is then never written or read.
+template <int KG, bool BN>
 __global__ __launch_bounds__(256, 2) void c_to_one_zwalk12_k(const float* __restrict__ a,
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ bias,
                                                              float* __restrict__ out, int N, int D, int H,
-                                                             int W, int flip, int nth, int ntw, int zsplit) {
+                                                             int W, int flip, int nth, int ntw, int zsplit,
+                                                             BnPrologue bn) {
     constexpr int C = 8 * KG;
     static_assert(ZX_TILES == 8, "two row tiles per wave");
     __shared__ float pim[2][ZX_TILES * 32 * C1_PP];    // all 256 rows of the eight tiles are written
+    __shared__ __attribute__((aligned(16))) float bnab[2][BN ? C : 4];
+    if (BN) {
+        if (threadIdx.x < C) bn_coeff(bn, threadIdx.x, bnab[0][threadIdx.x], bnab[1][threadIdx.x]);
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     float4 bw[KG];
@@ -591,7 +612,15 @@ __global__ __launch_bounds__(256, 2) void c_to_one_zwalk12_k(const float* __rest
             const bool ok0 = zin && okv[0], ok1 = zin && okv[1];
 #pragma unroll
             for (int g = 0; g < KG; ++g) {              // the two row tiles alternate: independent chains
-                const float4 v0 = av[par][0][g], v1 = av[par][1][g];
+                float4 v0 = av[par][0][g], v1 = av[par][1][g];
+                if (BN) {
+                    const float4 ca = *reinterpret_cast<const float4*>(&bnab[0][8 * g + 4 * h]);
+                    const float4 cb = *reinterpret_cast<const float4*>(&bnab[1][8 * g + 4 * h]);
+                    v0 = make_float4(bn_act1(v0.x, ca.x, cb.x, bn.slope), bn_act1(v0.y, ca.y, cb.y, bn.slope),
+                                     bn_act1(v0.z, ca.z, cb.z, bn.slope), bn_act1(v0.w, ca.w, cb.w, bn.slope));
+                    v1 = make_float4(bn_act1(v1.x, ca.x, cb.x, bn.slope), bn_act1(v1.y, ca.y, cb.y, bn.slope),
+                                     bn_act1(v1.z, ca.z, cb.z, bn.slope), bn_act1(v1.w, ca.w, cb.w, bn.slope));
+                }
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok0 ? v0.x : 0.f, bw[g].x, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok1 ? v1.x : 0.f, bw[g].x, acc[1], 0, 0, 0);
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ok0 ? v0.y : 0.f, bw[g].y, acc[0], 0, 0, 0);
@@ -703,16 +732,24 @@ __global__ __launch_bounds__(256) void thin_wg_k(const float* __restrict__ a,
 // eight 32-cycle matrix instructions.  The four waves are combined through LDS in fixed order and
 // one partial row per block is written, part[block][C][28], as above.
 // ---------------------------------------------------------------------------------
+template <bool BN>
 __global__ __launch_bounds__(256, 4) void thin_wg_mfma_k(const float* __restrict__ a,
                                                       const float* __restrict__ g,
                                                       float* __restrict__ part, int N, int D, int H, int W,
                                                       int C, int nbd, int nbh, int nbw,
-                                                      int bricks_per_block) {
+                                                      int bricks_per_block, BnPrologue bn) {
     __shared__ float hal[2][TH_V];
     __shared__ float red[64 * 28];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = lane & 15, kk = lane >> 4;
     const bool qok = 4 * q < C;
+    // BN: g is the raw output of the convolution in front; the lane's four channels get BatchNorm +
+    // LeakyReLU applied as they are loaded
+    float4 ca = make_float4(1.f, 1.f, 1.f, 1.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BN && qok) {
+        bn_coeff(bn, 4 * q + 0, ca.x, cb.x); bn_coeff(bn, 4 * q + 1, ca.y, cb.y);
+        bn_coeff(bn, 4 * q + 2, ca.z, cb.z); bn_coeff(bn, 4 * q + 3, ca.w, cb.w);
+    }
     // tap columns q and q + 16 of this lane: halo offset, or the constant column
     int toff[2];
     float bconst[2];
@@ -770,6 +807,9 @@ __global__ __launch_bounds__(256, 4) void thin_wg_mfma_k(const float* __restrict
                     bv[cg] = btap[cg] ? hp[dy * TH_W + dx0 + toff[cg]] : bconst[cg];
                 const bool ok = qok && y0 + dy < H && x0 + dx0 + kk < W;
                 float4 v = av[c4 & 1][u];
+                if (BN)
+                    v = make_float4(bn_act1(v.x, ca.x, cb.x, bn.slope), bn_act1(v.y, ca.y, cb.y, bn.slope),
+                                    bn_act1(v.z, ca.z, cb.z, bn.slope), bn_act1(v.w, ca.w, cb.w, bn.slope));
                 v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 #pragma unroll
                 for (int cg = 0; cg < 2; ++cg) {
@@ -868,6 +908,49 @@ long k3_thin_fwd_stat_blocks(int N, int D, int H, int W, int Ca, int Cb) {
     return nblk > 0x7fffffffL ? 0 : cdiv(nblk, bpb);
 }
 
+// 12 x 16 column walk of the 64 -> 1 kernel: applies to 64 channels on volumes of at least 16 x 12 x 16
+// unless 12-row columns pad H by 10 % more than 8-row ones; two blocks per CU
+struct ZxPlan {
+    int nth, ntw, zsplit;
+    long nb;
+};
+static bool zx_plan(int N, int D, int H, int W, int Ca, ZxPlan& p) {
+    if (!(Ca == 64 && D >= 16 && H >= 12 && W >= 16 && (long)H * W * Ca < (1L << 30) &&
+          cdiv(H, ZX_H) * ZX_H * 10 <= cdiv(H, ZW_H) * ZW_H * 11))
+        return false;
+    p.nth = (H + ZX_H - 1) / ZX_H, p.ntw = (W + ZX_W - 1) / ZX_W;
+    // z segments: each repeats two planes, and the two blocks of a CU share its matrix pipe --
+    // take the split with the fewest plane steps on the fullest CU
+    p.zsplit = 1;
+    long best = -1;
+    for (int zs = 1; zs <= D / 8; ++zs) {
+        const long rounds = cdiv((long)N * p.nth * p.ntw * zs, THIN_CUS);
+        const long cost = rounds * (cdiv(D, zs) + 2);
+        if (best < 0 || cost < best) best = cost, p.zsplit = zs;
+    }
+    p.nb = (long)N * p.nth * p.ntw * p.zsplit;
+    return p.nb <= 0x7fffffffL;
+}
+
+// C -> 1 forward with BatchNorm + LeakyReLU of the layer in front applied to the operand (x = that layer's
+// raw convolution output).  Only the column-walking kernel has this form.
+bool k3_thin_bn_fwd_supported(int N, int D, int H, int W, int Cin) {
+    ZxPlan zx;
+    return zx_plan(N, D, H, W, Cin, zx);
+}
+int k3_thin_bn_fwd_launch(const float* x, const BnPrologue& bn, const float* w, const float* bias, float* out,
+                          int N, int D, int H, int W, int Cin, hipStream_t s) {
+    ZxPlan zx;
+    if (!zx_plan(N, D, H, W, Cin, zx)) {
+        set_error("bnact_conv3d_k3_to1: unsupported shape (needs 64 channels, D >= 16, H >= 12, W >= 16)");
+        return SIV_EINVAL;
+    }
+    c_to_one_zwalk12_k<8, true><<<(unsigned)zx.nb, 256, 0, s>>>(x, w, bias, out, N, D, H, W, 0, zx.nth, zx.ntw,
+                                                               zx.zsplit, bn);
+    SIV_CHECK_LAUNCH("bnact_conv3d_k3_to1(fwd)");
+    return SIV_OK;
+}
+
 int k3_thin_fwd_launch(const float* a, const float* w, const float* bias, float* out, int N, int D,
                        int H, int W, int Ca, int Cb, int flip, hipStream_t s, float* stat_part) {
     const int nbd = (D + TB_D - 1) / TB_D, nbh = (H + TB_H - 1) / TB_H, nbw = (W + TB_W - 1) / TB_W;
@@ -903,25 +986,12 @@ int k3_thin_fwd_launch(const float* a, const float* w, const float* bias, float*
     // the matrix-core kernel runs one brick per block: with several, the barrier between the GEMM and
     // the gather phase of a brick serialises what independent blocks otherwise overlap (measured)
     const unsigned grid = (unsigned)nblk;
-    if (Ca == 64 && D >= 16 && H >= 12 && W >= 16 && (long)H * W * Ca < (1L << 30) &&
-        cdiv(H, ZX_H) * ZX_H * 10 <= cdiv(H, ZW_H) * ZW_H * 11) {
-        // 12 x 16 columns unless they pad H by 10 % more than 8 x 16 ones; two blocks per CU
-        const int nth = (H + ZX_H - 1) / ZX_H, ntw = (W + ZX_W - 1) / ZX_W;
-        // z segments: each repeats two planes, and the two blocks of a CU share its matrix pipe --
-        // take the split with the fewest plane steps on the fullest CU
-        int zsplit = 1;
-        long best = -1;
-        for (int zs = 1; zs <= D / 8; ++zs) {
-            const long rounds = cdiv((long)N * nth * ntw * zs, THIN_CUS);
-            const long cost = rounds * (cdiv(D, zs) + 2);
-            if (best < 0 || cost < best) best = cost, zsplit = zs;
-        }
-        const long nb = (long)N * nth * ntw * zsplit;
-        if (nb <= 0x7fffffffL) {
-            c_to_one_zwalk12_k<8><<<(unsigned)nb, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, nth, ntw, zsplit);
-            SIV_CHECK_LAUNCH("conv3d_k3(thin, z-walk 12x16)");
-            return SIV_OK;
-        }
+    ZxPlan zx;
+    if (zx_plan(N, D, H, W, Ca, zx)) {
+        c_to_one_zwalk12_k<8, false><<<(unsigned)zx.nb, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, zx.nth,
+                                                                    zx.ntw, zx.zsplit, BnPrologue{});
+        SIV_CHECK_LAUNCH("conv3d_k3(thin, z-walk 12x16)");
+        return SIV_OK;
     }
     if (Ca == 64 && D >= 16 && H >= 8 && W >= 16) {
         // long volumes: z-walking columns (less halo traffic); cut along z until ~1000 blocks
@@ -953,7 +1023,7 @@ int k3_thin_fwd_launch(const float* a, const float* w, const float* bias, float*
 
 int k3_thin_wgrad_launch(const float* x, const float* dy, float* dw, float* dbias, int N, int D, int H,
                          int W, int Cin, int Cout, int accumulate, void* ws, size_t ws_bytes,
-                         hipStream_t s) {
+                         hipStream_t s, const BnPrologue* bn) {
     const int nbd = (D + TB_D - 1) / TB_D, nbh = (H + TB_H - 1) / TB_H, nbw = (W + TB_W - 1) / TB_W;
     const long nbricks = (long)N * nbd * nbh * nbw;
     const int mode = (Cin == 1) ? 0 : 1;
@@ -972,8 +1042,15 @@ int k3_thin_wgrad_launch(const float* x, const float* dy, float* dw, float* dbia
     float* part = (float*)ws;
     const float* a = mode == 0 ? x : dy;
     const float* g = mode == 0 ? dy : x;
-    if (mfma)
-        thin_wg_mfma_k<<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb);
+    if (bn && !(mfma && mode == 1)) {
+        set_error("bnact_conv3d_k3_to1(wgrad): needs at most 64 input channels");
+        return SIV_EINVAL;
+    }
+    if (mfma && bn)
+        thin_wg_mfma_k<true><<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb, *bn);
+    else if (mfma)
+        thin_wg_mfma_k<false><<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb,
+                                                            BnPrologue{});
     else
         thin_wg_k<<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb);
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(thin)");

@@ -143,7 +143,10 @@ long k3_thin_fwd_stat_blocks(int N, int D, int H, int W, int Ca, int Cb);
 int k3_thin_fwd_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int,
                        int flip, hipStream_t, float* stat_part);
 int k3_thin_wgrad_launch(const float*, const float*, float*, float*, int, int, int, int, int, int,
-                         int, void*, size_t, hipStream_t);
+                         int, void*, size_t, hipStream_t, const BnPrologue* bn);
+bool k3_thin_bn_fwd_supported(int N, int D, int H, int W, int Cin);
+int k3_thin_bn_fwd_launch(const float* x, const BnPrologue& bn, const float* w, const float* bias, float* out,
+                          int N, int D, int H, int W, int Cin, hipStream_t s);
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -214,7 +217,7 @@ using namespace siv;
 
 extern "C" const char* siv_last_error(void) { return g_err; }
 extern "C" const char* siv_last_conv_kernel(void) { return g_conv_kernel; }
-extern "C" int siv_version(void) { return 102; }
+extern "C" int siv_version(void) { return 103; }
 extern "C" size_t siv_workspace_bytes(void) { return (size_t)512 << 20; }
 extern "C" int siv_pack_cache_configure(void* mem, size_t bytes) {
     SIV_CHECK_ARG(((uintptr_t)mem & 255) == 0, "pack_cache_configure: memory must be 256-byte aligned");
@@ -345,6 +348,39 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
                         ws_bytes, stream);
 }
 
+// BatchNorm + LeakyReLU of the layer in front folded into a Cin -> 1 convolution (the decoder's output layer
+// behind its last block): x is that block's raw convolution output, the activated tensor is never formed.
+extern "C" int siv_bnact_conv3d_k3_to1_supported(int N, int D, int H, int W, int Cin) {
+    return conv_path() != 1 && k3_thin_bn_fwd_supported(N, D, H, W, Cin) ? 1 : 0;
+}
+extern "C" int siv_bnact_conv3d_k3_to1_fwd(const float* x, const float* mean, const float* var,
+                                           const float* gamma, const float* beta, float eps, float slope,
+                                           const float* w, const float* bias, float* y, int N, int D, int H,
+                                           int W, int Cin, siv_stream_t stream) {
+    SIV_CHECK_ARG(x && mean && var && gamma && beta && w && y, "bnact_conv3d_k3_to1_fwd: null pointer");
+    int rc = check_conv_shape("bnact_conv3d_k3_to1_fwd", N, D, H, W, Cin, 1, 1);
+    if (rc) return rc;
+    SIV_CHECK_ARG(aligned16(x) && aligned16(w), "bnact_conv3d_k3_to1_fwd: x and w must be 16-byte aligned");
+    SIV_PICK("thin");
+    return k3_thin_bn_fwd_launch(x, BnPrologue{mean, var, gamma, beta, eps, slope}, w, bias, y, N, D, H, W, Cin,
+                                 (hipStream_t)stream);
+}
+extern "C" int siv_bnact_conv3d_k3_to1_wgrad(const float* x, const float* mean, const float* var,
+                                             const float* gamma, const float* beta, float eps, float slope,
+                                             const float* dy, float* dw, float* dbias, int N, int D, int H,
+                                             int W, int Cin, int accumulate, void* ws, size_t ws_bytes,
+                                             siv_stream_t stream) {
+    SIV_CHECK_ARG(x && mean && var && gamma && beta && dy && dw, "bnact_conv3d_k3_to1_wgrad: null pointer");
+    int rc = check_conv_shape("bnact_conv3d_k3_to1_wgrad", N, D, H, W, Cin, 1, 1);
+    if (rc) return rc;
+    SIV_CHECK_ARG(Cin % 4 == 0 && Cin <= 64 && aligned16(x),
+                  "bnact_conv3d_k3_to1_wgrad: needs Cin %% 4 == 0, Cin <= 64 and a 16-byte aligned x");
+    const BnPrologue bn{mean, var, gamma, beta, eps, slope};
+    SIV_PICK("thin");
+    return k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, 1, accumulate, ws, ws_bytes,
+                                (hipStream_t)stream, &bn);
+}
+
 // Input gradient of the 3x3x3 convolution = forward convolution of dy with the flipped, transposed
 // weights; `bias` (per dx channel, may be NULL) makes the same call a transposed convolution.
 static int dgrad_dispatch(const char* what, const float* dy, const float* w, const float* bias, float* dx,
@@ -440,7 +476,7 @@ extern "C" int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, f
     const int path = conv_path();
     const bool al = aligned16(x) && aligned16(dy) && aligned16(dw) && aligned16(ws);
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
-        return SIV_PICK("thin"), k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s);
+        return SIV_PICK("thin"), k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s, nullptr);
     if (use_gw(path, al, ups, N, D, H, W, Cin, Cout)) {
         SIV_PICK(ups == 2 ? "up_wino" : "wino2d");
         rc = ups == 2 ? k2_up_wgrad_wino_launch(x, dy, dw, N, D, H, W, Cin, Cout, accumulate, ws, ws_bytes, s)

@@ -46,6 +46,16 @@ enum PackFamily { PF_MFMA = 1, PF_WINO, PF_WINO_B3, PF_WINO2D, PF_UP_PROD, PF_UP
 void* pack_slot(const void* w, int family, int variant, int flip, int Cin, int Cout, size_t bytes, void* ws,
                 bool* need_pack);
 
+// BatchNorm of the layer in front, for kernels that apply it (and the LeakyReLU behind it) to their
+// operand instead of reading an activated tensor
+struct BnPrologue {
+    const float* mean;
+    const float* var;
+    const float* gamma;
+    const float* beta;
+    float eps, slope;
+};
+
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 

@@ -211,6 +211,38 @@ class HipBackend:
                                                 ws, wsb, self._stream(dy)), "siv_conv3d_k3_wgrad")
         return dw, db
 
+    # ---- BatchNorm + LeakyReLU folded into the Cin -> 1 convolution behind them ---------------------
+    def bnact_conv_to1_supported(self, x) -> bool:
+        """True when ``bnact_conv_to1_fwd`` has a kernel for the raw convolution output ``x``."""
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5):
+            return False
+        N, C, D, H, W = x.shape
+        return bool(self.lib.siv_bnact_conv3d_k3_to1_supported(N, D, H, W, C))
+
+    def bnact_conv_to1_fwd(self, x, mean, var, gamma, beta, eps: float, slope: float, w, bias):
+        self._check_dev(x, mean, var, gamma, beta, w, bias)
+        x, w = cl(x), cl(w)
+        N, C, D, H, W = x.shape
+        assert tuple(w.shape) == (1, C, 3, 3, 3), tuple(w.shape)
+        y = empty_cl((N, 1, D, H, W), x)
+        _lib.check(self.lib.siv_bnact_conv3d_k3_to1_fwd(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), eps, slope,
+                                                        _p(w), _p(bias), _p(y), N, D, H, W, C, self._stream(x)),
+                   "siv_bnact_conv3d_k3_to1_fwd")
+        return y
+
+    def bnact_conv_to1_wgrad(self, x, mean, var, gamma, beta, eps: float, slope: float, dy,
+                             want_bias: bool = False, dw_out=None, db_out=None):
+        self._check_dev(x, mean, var, gamma, beta, dy, dw_out, db_out)
+        x, dy = cl(x), cl(dy)
+        N, C, D, H, W = x.shape
+        dw, db, acc = self._grad_targets((1, C, 3, 3, 3), dy, want_bias, dw_out, db_out)
+        ws, wsb = self._workspace(dy)
+        _lib.check(self.lib.siv_bnact_conv3d_k3_to1_wgrad(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), eps, slope,
+                                                          _p(dy), _p(dw), _p(db), N, D, H, W, C, acc, ws, wsb,
+                                                          self._stream(dy)),
+                   "siv_bnact_conv3d_k3_to1_wgrad")
+        return dw, db
+
     def last_conv_kernel(self) -> str:
         """Kernel family the last 3x3x3 convolution call of this thread ran on."""
         return self.lib.siv_last_conv_kernel().decode()

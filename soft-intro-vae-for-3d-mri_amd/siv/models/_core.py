@@ -119,6 +119,15 @@ class UpsampleBuildingkBlock(_ResBlockBase):
         h = ops.conv_bn_act(x, c1, b1, s, train=self.training)
         return ops.conv_bn_act(h, c2, b2, s, ups=self.stride, residual=self._res(x), train=self.training)
 
+    def forward_unnormalised(self, x):
+        """The block up to and including its second convolution: (raw output, batch statistics or None).
+        For a consumer that applies this block's closing BatchNorm + activation itself (no residual)."""
+        c1, b1, _, _, c2, b2 = self.block
+        if self.res or self.stride not in (1, 2):
+            raise ValueError("only for blocks without a residual connection")
+        h = ops.conv_bn_act(x, c1, b1, self.variant.slope, train=self.training)
+        return ops.conv_with_stats(h, c2, b2, ups=self.stride, train=self.training)
+
 
 class ResNetEncoder(nn.Module):
     """models/models.py:83-108: stem conv3(1->in_ch)+BN+act(+Dropout), BuildingBlock stack,
@@ -206,10 +215,22 @@ class ResNetDecoder(nn.Module):
         h = ops.conv1x1(z, conv.weight, conv.bias)
         keep = _keep(h.shape, v.p_dec_stem, self.training, h.device)
         h = ops.bn_act(h, bn, v.slope, keep=keep, p=v.p_dec_stem, train=self.training)
-        for blk in mods[1:-1]:
+        for blk in mods[1:-2]:
             h = blk[0](h)
-        conv = mods[-1][0]
-        h = ops.conv3d_k3(h, conv.weight, conv.bias)
+        last, conv = mods[-2][0], mods[-1][0]
+        y = stats = None
+        if len(mods) > 2 and isinstance(last, UpsampleBuildingkBlock) and not last.res and conv.out_channels == 1:
+            # the last block's closing BatchNorm + activation can run inside the output convolution
+            y, stats = last.forward_unnormalised(h)
+            if not ops.bn_act_conv_to1_supported(y):
+                h = ops.bn_act(y, last.block[5], v.slope, train=self.training, stats=stats)
+                y = None
+        elif len(mods) > 2:
+            h = last(h)
+        if y is not None:
+            h = ops.bn_act_conv_to1(y, last.block[5], v.slope, conv, self.training, stats)
+        else:
+            h = ops.conv3d_k3(h, conv.weight, conv.bias)
         keep = _keep(h.shape, v.p_dec_out, self.training, h.device)
         return ops.act_dropout(h, 0.0, keep=keep, p=v.p_dec_out)   # nn.ReLU then nn.Dropout
 

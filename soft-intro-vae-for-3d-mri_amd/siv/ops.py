@@ -291,6 +291,80 @@ def conv_bn_act(x, conv, bn, slope: float, ups: int = 1, pool: int = 1, residual
     return bn_act(y, bn, slope, pool, residual, keep, p, False)
 
 
+class _BnActConvTo1(Function):
+    """BatchNorm3d -> LeakyReLU -> Conv3d(C, 1, 3, 1, 1) with the first two applied while the convolution
+    loads its operand: the activated C-channel tensor is neither written nor read, in forward or in the
+    weight gradient.  Backward = input gradient of the convolution, its weight gradient (same prologue),
+    then BatchNorm's own backward."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, w, bias, bn, slope, train, stats):
+        B = get_backend()
+        mean, var = stats if train else (bn.running_mean, bn.running_var)
+        out = B.bnact_conv_to1_fwd(y, mean, var, gamma, beta, bn.eps, slope, w, bias)
+        ctx.save_for_backward(y, mean, var, gamma, beta, w)
+        ctx.cfg = (slope, bn.eps, train, bias is not None)
+        ctx.bufs = (_grad_buf(gamma), _grad_buf(beta), _grad_buf(w), _grad_buf(bias))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, mean, var, gamma, beta, w = ctx.saved_tensors
+        slope, eps, train, has_bias = ctx.cfg
+        g_buf, b_buf, w_buf, cb_buf = ctx.bufs
+        if not train:
+            raise NotImplementedError("backward through evaluation-mode BatchNorm is not part of the "
+                                      "training path (the reference validates under torch.no_grad())")
+        B = get_backend()
+        dy = dg = db = dw = dcb = None
+        want_cb = has_bias and ctx.needs_input_grad[4]
+        if ctx.needs_input_grad[3] or want_cb:
+            direct = ctx.needs_input_grad[3] and w_buf is not None and (not want_cb or cb_buf is not None)
+            if direct:
+                _wgrad_on_side_stream(B, y, dout, _side_ready(B, dout), lambda: B.bnact_conv_to1_wgrad(
+                    y, mean, var, gamma, beta, eps, slope, dout, want_cb, w_buf, cb_buf))
+            else:
+                dw, dcb = B.bnact_conv_to1_wgrad(y, mean, var, gamma, beta, eps, slope, dout, want_cb)
+                if not ctx.needs_input_grad[3]:
+                    dw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            da = B.conv3d_k3_dgrad(dout, w, 1)             # gradient of the activation that was never stored
+            want_aff = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+            if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and g_buf is not None and b_buf is not None:
+                dy, _, _, _ = B.bn_act_bwd(da, y, mean, var, gamma, beta, None, None, 0.0, slope, 1, eps, True,
+                                           False, g_buf, b_buf)
+            else:
+                dy, dg, db, _ = B.bn_act_bwd(da, y, mean, var, gamma, beta, None, None, 0.0, slope, 1, eps,
+                                             want_aff, False)
+            if not ctx.needs_input_grad[0]:
+                dy = None
+        return (dy, dg if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None, dw, dcb,
+                None, None, None, None)
+
+
+def bn_act_conv_to1_supported(y) -> bool:
+    B = get_backend()
+    return hasattr(B, "bnact_conv_to1_supported") and B.bnact_conv_to1_supported(y)
+
+
+def bn_act_conv_to1(y, bn, slope: float, conv, train: bool = True, stats=None):
+    """``conv(LeakyReLU(bn(y)))`` for a ``Conv3d(C, 1, 3, 1, 1)`` module ``conv`` as one fused operator
+    (``bn_act_conv_to1_supported(y)`` tells whether the shape has a kernel); ``stats`` as in ``bn_act``."""
+    if train and stats is None:
+        B = get_backend()
+        stats = B.bn_stats(y, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                           BN_MOMENTUM if bn.momentum is None else bn.momentum)
+    return _BnActConvTo1.apply(y, bn.weight, bn.bias, conv.weight, conv.bias, bn, slope, train, stats)
+
+
+def conv_with_stats(x, conv, bn, ups: int = 1, train: bool = True):
+    """The convolution half of ``conv_bn_act``: (raw output, (mean, var) or None)."""
+    if train:
+        y, mean, var = _Conv3dK3.apply(x, conv.weight, conv.bias, ups, bn)
+        return y, (mean, var)
+    return _Conv3dK3.apply(x, conv.weight, conv.bias, ups, None), None
+
+
 class _ActDropout(Function):
     @staticmethod
     def forward(ctx, x, keep, p, slope):

@@ -485,6 +485,71 @@ def test_conv_fwd_with_bn_statistics(B, cin, cout, dims, n, ups, path, use_bias)
     assert int(nbt) == 5
 
 
+@pytest.mark.parametrize("dims,n", [((16, 24, 32), 2), ((19, 44, 36), 1), ((16, 12, 16), 3)])
+def test_bnact_conv_to1_matches_separate_ops(B, dims, n):
+    """BatchNorm + LeakyReLU folded into the 64 -> 1 output convolution (models/models.py:76-78,137):
+    forward and weight gradient against the oracle's conv(leaky_relu(batch_norm(x))) in float64, the
+    operator through autograd against the unfused operators (bn_act + conv3d_k3) on the same inputs, the
+    shapes without a kernel reported as unsupported."""
+    import siv.ops as ops
+    gen = torch.Generator().manual_seed(dims[1] + n)
+    D, H, W = dims
+    C, slope, eps = 64, 0.2, 1e-5
+    x = rnd(gen, n, C, D, H, W) * 1.5 + 0.2
+    gamma, beta = 1 + 0.3 * rnd(gen, C), 0.2 * rnd(gen, C)
+    w, b = rnd(gen, 1, C, 3, 3, 3, scale=(2.0 / (27 * C)) ** 0.5), rnd(gen, 1)
+    dy = rnd(gen, n, 1, D, H, W)
+    mean = x.double().mean(dim=(0, 2, 3, 4))
+    var = x.double().var(dim=(0, 2, 3, 4), unbiased=False)
+    assert B.bnact_conv_to1_supported(dev(x))
+    assert not B.bnact_conv_to1_supported(dev(x[:, :32])) and not B.bnact_conv_to1_supported(dev(x[:, :, :8]))
+    # float64 reference of the composition
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    mg = xd.mean(dim=(0, 2, 3, 4), keepdim=True)             # batch statistics inside the graph
+    vg = xd.var(dim=(0, 2, 3, 4), unbiased=False, keepdim=True)
+    a = F.leaky_relu((xd - mg) / torch.sqrt(vg + eps) * gamma.double().view(1, -1, 1, 1, 1)
+                     + beta.double().view(1, -1, 1, 1, 1), slope)
+    yr = F.conv3d(a, wd, b.double(), padding=1)
+    yr.backward(dy.double())
+    args = (dev(x), dev(mean.float()), dev(var.float()), dev(gamma), dev(beta), eps, slope)
+    y = B.bnact_conv_to1_fwd(*args, dev(w), dev(b))
+    check(y, yr.detach().float(), "fused forward")
+    dw, db = B.bnact_conv_to1_wgrad(*args, dev(dy), True)
+    check(dw, wd.grad.float(), "fused weight gradient")
+    check(db, dy.double().sum().reshape(1).float(), "bias gradient")
+    acc = dev(torch.ones_like(w)).contiguous(memory_format=torch.channels_last_3d)
+    B.bnact_conv_to1_wgrad(*args, dev(dy), False, acc, None)
+    check(acc, 1 + wd.grad.float(), "fused weight gradient, accumulated")
+
+    # the autograd operator against the unfused operators: same statistics, same parameters
+    class _Bn(torch.nn.BatchNorm3d):
+        pass
+    outs = []
+    for fused in (True, False):
+        bn = _Bn(C).to("cuda").train()
+        conv = torch.nn.Conv3d(C, 1, 3, 1, 1).to("cuda")
+        with torch.no_grad():
+            bn.weight.copy_(dev(gamma)); bn.bias.copy_(dev(beta))
+            conv.weight.copy_(dev(w)); conv.bias.copy_(dev(b))
+        conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last_3d)
+        xg = dev(x).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        if fused:
+            out = ops.bn_act_conv_to1(xg, bn, slope, conv, True, None)
+        else:
+            out = ops.conv3d_k3(ops.bn_act(xg, bn, slope, train=True), conv.weight, conv.bias)
+        out.backward(dev(dy))
+        outs.append((out.detach(), xg.grad, bn.weight.grad, bn.bias.grad, conv.weight.grad, conv.bias.grad,
+                     bn.running_mean.clone(), bn.running_var.clone()))
+    for a_, b_, what in zip(outs[0], outs[1], ("out", "dx", "dgamma", "dbeta", "dw", "dbias", "running mean",
+                                               "running var")):
+        check(a_, b_, "operator: " + what, tol=2e-5)
+    check(outs[0][1], xd.grad.float(), "dx against float64")
+    import siv._lib as L
+    with pytest.raises(L.SivError):
+        B.bnact_conv_to1_fwd(dev(x[:, :, :8].contiguous()), *args[1:], dev(w), dev(b))
+
+
 # nn.ConvTranspose3d(k=3, s=1, p=1): the shapes of models/model.py:202-205 (Decoder_lucky: 8 -> 16 -> 32 -> 64 -> 1
 # on 32 x 24 x 32 volumes ... scaled down in extent for the CPU reference), an odd shape for the generic path and
 # one large enough for the Winograd kernels
