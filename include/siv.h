@@ -128,13 +128,22 @@ int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, float* dbias
  * padding of the activated tensor while they load x, so the activated full-resolution tensor is never
  * written or read.  _fwd: y[N][D][H][W] = conv(act(bn(x)), w[1][27][Cin]) + bias.  _wgrad: dw[1][27][Cin]
  * (+ dbias[1]) from dy[N][D][H][W] and the same x.  The gradient with respect to the activation is the
- * plain siv_conv3d_k3_dgrad of dy; BatchNorm's own backward (siv_bn_act_bwd) takes it from there.
+ * plain siv_conv3d_k3_dgrad of dy; BatchNorm's own backward (siv_bn_act_bwd) takes it from there --
+ * or _dgrad does both at once: dx = gradient of the RAW tensor x (what siv_bn_act_bwd would return as
+ * dy), dgamma / dbeta written or, with accumulate = 1, added to; the gradient of the activation is
+ * recomputed in registers by both of its passes (27 multiply-adds per element on the matrix pipe)
+ * instead of being written once and read twice.  Cin % 4 == 0, Cin <= 64.
  * _supported: 1 when _fwd has a kernel for the shape (64 channels, D >= 16, H >= 12, W >= 16). */
 int siv_bnact_conv3d_k3_to1_supported(int N, int D, int H, int W, int Cin);
 int siv_bnact_conv3d_k3_to1_fwd(const float* x, const float* mean, const float* var, const float* gamma,
                                 const float* beta, float eps, float slope, const float* w,
                                 const float* bias, float* y, int N, int D, int H, int W, int Cin,
                                 siv_stream_t stream);
+int siv_bnact_conv3d_k3_to1_dgrad(const float* dy, const float* w, const float* x, const float* mean,
+                                  const float* var, const float* gamma, const float* beta, float eps,
+                                  float slope, float* dx, float* dgamma, float* dbeta, int accumulate,
+                                  int N, int D, int H, int W, int Cin, void* ws, size_t ws_bytes,
+                                  siv_stream_t stream);
 int siv_bnact_conv3d_k3_to1_wgrad(const float* x, const float* mean, const float* var, const float* gamma,
                                   const float* beta, float eps, float slope, const float* dy, float* dw,
                                   float* dbias, int N, int D, int H, int W, int Cin, int accumulate,

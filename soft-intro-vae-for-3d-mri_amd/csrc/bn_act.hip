@@ -713,6 +713,13 @@ int bn_finalize_launch(const float* shift, const float* part, int nblk, long M, 
     SIV_CHECK_LAUNCH("bn_stats(finalize)");
     return SIV_OK;
 }
+// for kernels in other files that produce the [block][2][C] partials of (sum dz, sum dz*xhat) themselves
+int bn_bwd_finalize_launch(const float* part, int nblk, int C, float* sums, float* dgamma, float* dbeta,
+                           int accumulate, hipStream_t s) {
+    bn_bwd_finalize<<<(C + 3) / 4, 256, 0, s>>>(part, nblk, C, sums, dgamma, dbeta, accumulate);
+    SIV_CHECK_LAUNCH("bn_bwd(finalize)");
+    return SIV_OK;
+}
 }  // namespace siv
 
 extern "C" int siv_bn_act_fwd(const float* y, const float* mean, const float* var,

@@ -204,6 +204,137 @@ __global__ __launch_bounds__(256, 4) void one_to_c_mfma_k(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------
+// Backward of [BatchNorm + LeakyReLU] -> Conv3d(C, 1, 3) with respect to the BatchNorm input, without the
+// gradient of the activation ever reaching memory.  That gradient, da[v][c] = sum_tap g1[v - tap + 1] *
+// w[tap][c], is the 1 -> C kernel above applied to the single-channel output gradient g1 -- 27
+// multiply-adds per element on the matrix pipe -- so both passes of the BatchNorm backward recompute it
+// in registers instead of one kernel writing it (157 MB per volume) and two reading it:
+//   STAGE 0: dz = da * act'(z), z = y*a + b;  per-block sums of dz and dz * xhat  -> part[block][2][C]
+//   STAGE 1: dy = a * (dz - sum(dz)/M - xhat * sum(dz*xhat)/M)                     (sums[2][C] finalised)
+// Layout and tiling as one_to_c_mfma_k: a lane holds channels 4q .. 4q+3 of voxels 4 kk + e.
+// ---------------------------------------------------------------------------------
+template <int STAGE>
+__global__ __launch_bounds__(256, 3) void tail_bn_bwd_k(const float* __restrict__ g1,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ y, BnPrologue bn,
+                                                        const float* __restrict__ sums, float invM,
+                                                        float* __restrict__ part, float* __restrict__ dy,
+                                                        int N, int D, int H, int W, int C, int nbd, int nbh,
+                                                        int nbw, int bricks_per_block, int nbricks) {
+    __shared__ float hal[2][TH_V];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = lane & 15, kk = lane >> 4;
+    const bool qok = 4 * q < C;
+    float wb[7][4];
+    int toff[7];
+#pragma unroll
+    for (int st = 0; st < 7; ++st) {
+        const int t = 4 * st + kk;
+        toff[st] = t < 27 ? ((t / 9) * TH_H + (t / 3) % 3) * TH_W + t % 3 : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)     // input gradient: w is [1][27][C], taps reversed
+            wb[st][j] = (t < 27 && qok) ? w[(26 - t) * C + 4 * q + j] : 0.f;
+    }
+    float ca[4], cb[4], cm[4], ci[4], k1[4], k2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = qok ? 4 * q + j : 0;
+        ci[j] = 1.0f / sqrtf(bn.var[c] + bn.eps);
+        ca[j] = bn.gamma[c] * ci[j];
+        cm[j] = bn.mean[c];
+        cb[j] = bn.beta[c] - cm[j] * ca[j];
+        k1[j] = STAGE == 1 ? sums[c] * invM : 0.f;
+        k2[j] = STAGE == 1 ? sums[C + c] * invM : 0.f;
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int b0 = blockIdx.x * bricks_per_block;
+    const int b1 = b0 + bricks_per_block < nbricks ? b0 + bricks_per_block : nbricks;
+    int buf = 0;
+    for (int br = b0; br < b1; ++br, buf ^= 1) {
+        int n, z0, y0, x0;
+        brick_coords(br, nbd, nbh, nbw, n, z0, y0, x0);
+        load_halo1(g1, hal[buf], n, z0, y0, x0, D, H, W);
+        __syncthreads();
+        const int gz = z0 + wv;
+        if (gz >= D) continue;
+        const long base = ((((long)n * D + gz) * H + y0) * W + x0) * C + 4 * q;
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {                // 16 voxels = brick rows 2 tl, 2 tl + 1
+            // this lane's four voxels of the tile: y goes out first and has the products to arrive
+            float4 yv[4];
+            bool ok[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = 4 * kk + e;
+                const int dyy = 2 * tl + (m >> 3), dx = m & 7;
+                ok[e] = qok && y0 + dyy < H && x0 + dx < W;
+                yv[e] = *reinterpret_cast<const float4*>(ok[e] ? y + base + ((long)dyy * W + dx) * C : y);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float* hp = hal[buf] + (wv * TH_H + 2 * tl + (q >> 3)) * TH_W + (q & 7);
+            float av[7];
+#pragma unroll
+            for (int st = 0; st < 7; ++st) av[st] = hp[toff[st]];
+            f32x4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 7; ++st)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], wb[st][j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float yy[4] = {yv[e].x, yv[e].y, yv[e].z, yv[e].w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float z = fmaf(yy[j], ca[j], cb[j]);
+                    const float dz = acc[j][e] * (z > 0.f ? 1.f : bn.slope);
+                    const float xh = (yy[j] - cm[j]) * ci[j];
+                    if (STAGE == 0) {
+                        if (ok[e]) {
+                            s1[j] += dz;
+                            s2[j] = fmaf(dz, xh, s2[j]);
+                        }
+                    } else {
+                        o[j] = ca[j] * (dz - k1[j] - xh * k2[j]);
+                    }
+                }
+                if (STAGE == 1 && ok[e]) {
+                    const int m = 4 * kk + e;
+                    *reinterpret_cast<float4*>(dy + base + ((long)(2 * tl + (m >> 3)) * W + (m & 7)) * C) =
+                        make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    }
+    if (STAGE == 0) {           // part[block][2][C]: the four lanes of a channel quad, then the four waves
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 16; o < 64; o <<= 1) {
+                s1[j] += __shfl_xor(s1[j], o, 64);
+                s2[j] += __shfl_xor(s2[j], o, 64);
+            }
+        __syncthreads();
+        float* red = hal[0];                   // [4 waves][2][64 channels]
+        if (lane < 16) {
+            *reinterpret_cast<float4*>(red + (wv * 2 + 0) * 64 + 4 * q) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+            *reinterpret_cast<float4*>(red + (wv * 2 + 1) * 64 + 4 * q) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int k = threadIdx.x >> 6, c = threadIdx.x & 63;
+            if (c < C)
+                part[((long)blockIdx.x * 2 + k) * C + c] =
+                    (red[(0 * 2 + k) * 64 + c] + red[(1 * 2 + k) * 64 + c]) +
+                    (red[(2 * 2 + k) * 64 + c] + red[(3 * 2 + k) * 64 + c]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // c_to_one.  Stage 1: p[u][tap] = <a[u][:], wk[tap][:]> for every halo voxel u, channels
 // streamed through LDS in chunks of 8 with each thread keeping the 27 running dots of its
 // voxels in registers.  Stage 2: out[v] = b + sum_tap p[v+tap-1][tap].
@@ -733,7 +864,7 @@ __global__ __launch_bounds__(256) void thin_wg_k(const float* __restrict__ a,
 // one partial row per block is written, part[block][C][28], as above.
 // ---------------------------------------------------------------------------------
 template <bool BN>
-__global__ __launch_bounds__(256, 4) void thin_wg_mfma_k(const float* __restrict__ a,
+__global__ __launch_bounds__(256, BN ? 3 : 4) void thin_wg_mfma_k(const float* __restrict__ a,
                                                       const float* __restrict__ g,
                                                       float* __restrict__ part, int N, int D, int H, int W,
                                                       int C, int nbd, int nbh, int nbw,
@@ -948,6 +1079,43 @@ int k3_thin_bn_fwd_launch(const float* x, const BnPrologue& bn, const float* w, 
     c_to_one_zwalk12_k<8, true><<<(unsigned)zx.nb, 256, 0, s>>>(x, w, bias, out, N, D, H, W, 0, zx.nth, zx.ntw,
                                                                zx.zsplit, bn);
     SIV_CHECK_LAUNCH("bnact_conv3d_k3_to1(fwd)");
+    return SIV_OK;
+}
+
+int bn_bwd_finalize_launch(const float* part, int nblk, int C, float* sums, float* dgamma, float* dbeta,
+                           int accumulate, hipStream_t s);
+
+// dx (= gradient of the BatchNorm input), dgamma, dbeta of [BatchNorm + LeakyReLU] -> Conv3d(Cin, 1, 3)
+// from the convolution's output gradient g1[N][D][H][W]
+int k3_thin_bn_dgrad_launch(const float* g1, const float* w, const float* x, const BnPrologue& bn, float* dx,
+                            float* dgamma, float* dbeta, int accumulate, int N, int D, int H, int W, int Cin,
+                            void* ws, size_t ws_bytes, hipStream_t s) {
+    if (Cin % 4 != 0 || Cin > 64) {
+        set_error("bnact_conv3d_k3_to1(dgrad): needs Cin %% 4 == 0 and Cin <= 64 (got %d)", Cin);
+        return SIV_EINVAL;
+    }
+    const int nbd = (D + TB_D - 1) / TB_D, nbh = (H + TB_H - 1) / TB_H, nbw = (W + TB_W - 1) / TB_W;
+    long nbricks;
+    int bpb;
+    thin_1c_grid(N, D, H, W, nbricks, bpb);
+    if (nbricks > 0x7fffffffL) {
+        set_error("bnact_conv3d_k3_to1(dgrad): too many bricks");
+        return SIV_EINVAL;
+    }
+    const long nblk = cdiv(nbricks, bpb);
+    const size_t part_bytes = align256((size_t)nblk * 2 * Cin * sizeof(float));
+    SIV_CHECK_WS(part_bytes + (size_t)2 * Cin * sizeof(float), ws_bytes, "bnact_conv3d_k3_to1(dgrad)");
+    float* part = (float*)ws;
+    float* sums = (float*)((char*)ws + part_bytes);
+    const float invM = 1.0f / (float)((long)N * D * H * W);
+    tail_bn_bwd_k<0><<<(unsigned)nblk, 256, 0, s>>>(g1, w, x, bn, nullptr, invM, part, nullptr, N, D, H, W, Cin, nbd,
+                                                   nbh, nbw, bpb, (int)nbricks);
+    SIV_CHECK_LAUNCH("bnact_conv3d_k3_to1(dgrad, sums)");
+    const int rc = bn_bwd_finalize_launch(part, (int)nblk, Cin, sums, dgamma, dbeta, accumulate, s);
+    if (rc) return rc;
+    tail_bn_bwd_k<1><<<(unsigned)nblk, 256, 0, s>>>(g1, w, x, bn, sums, invM, nullptr, dx, N, D, H, W, Cin, nbd, nbh,
+                                                   nbw, bpb, (int)nbricks);
+    SIV_CHECK_LAUNCH("bnact_conv3d_k3_to1(dgrad, apply)");
     return SIV_OK;
 }
 

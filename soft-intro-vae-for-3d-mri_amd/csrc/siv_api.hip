@@ -144,6 +144,9 @@ int k3_thin_fwd_launch(const float*, const float*, const float*, float*, int, in
                        int flip, hipStream_t, float* stat_part);
 int k3_thin_wgrad_launch(const float*, const float*, float*, float*, int, int, int, int, int, int,
                          int, void*, size_t, hipStream_t, const BnPrologue* bn);
+int k3_thin_bn_dgrad_launch(const float* g1, const float* w, const float* x, const BnPrologue& bn, float* dx,
+                            float* dgamma, float* dbeta, int accumulate, int N, int D, int H, int W, int Cin,
+                            void* ws, size_t ws_bytes, hipStream_t s);
 bool k3_thin_bn_fwd_supported(int N, int D, int H, int W, int Cin);
 int k3_thin_bn_fwd_launch(const float* x, const BnPrologue& bn, const float* w, const float* bias, float* out,
                           int N, int D, int H, int W, int Cin, hipStream_t s);
@@ -379,6 +382,23 @@ extern "C" int siv_bnact_conv3d_k3_to1_wgrad(const float* x, const float* mean, 
     SIV_PICK("thin");
     return k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, 1, accumulate, ws, ws_bytes,
                                 (hipStream_t)stream, &bn);
+}
+
+extern "C" int siv_bnact_conv3d_k3_to1_dgrad(const float* dy, const float* w, const float* x,
+                                             const float* mean, const float* var, const float* gamma,
+                                             const float* beta, float eps, float slope, float* dx,
+                                             float* dgamma, float* dbeta, int accumulate, int N, int D, int H,
+                                             int W, int Cin, void* ws, size_t ws_bytes, siv_stream_t stream) {
+    SIV_CHECK_ARG(dy && w && x && mean && var && gamma && beta && dx, "bnact_conv3d_k3_to1_dgrad: null pointer");
+    int rc = check_conv_shape("bnact_conv3d_k3_to1_dgrad", N, D, H, W, Cin, 1, 1);
+    if (rc) return rc;
+    SIV_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr),
+                  "bnact_conv3d_k3_to1_dgrad: dgamma and dbeta must both be given or both be NULL");
+    SIV_CHECK_ARG(aligned16(x) && aligned16(dx) && aligned16(ws),
+                  "bnact_conv3d_k3_to1_dgrad: x, dx and the workspace must be 16-byte aligned");
+    SIV_PICK("thin");
+    return k3_thin_bn_dgrad_launch(dy, w, x, BnPrologue{mean, var, gamma, beta, eps, slope}, dx, dgamma, dbeta,
+                                   accumulate, N, D, H, W, Cin, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // Input gradient of the 3x3x3 convolution = forward convolution of dy with the flipped, transposed

@@ -28,6 +28,7 @@ SIGNATURES = {
     "siv_conv_transpose3d_k3_wgrad": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_bnact_conv3d_k3_to1_supported": [_i, _i, _i, _i, _i],
     "siv_bnact_conv3d_k3_to1_fwd": [_f, _f, _f, _f, _f, _fl, _fl, _f, _f, _f, _i, _i, _i, _i, _i, _f],
+    "siv_bnact_conv3d_k3_to1_dgrad": [_f, _f, _f, _f, _f, _f, _f, _fl, _fl, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_bnact_conv3d_k3_to1_wgrad": [_f, _f, _f, _f, _f, _fl, _fl, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_upsample2_bwd": [_f, _f, _i, _i, _i, _i, _i, _f],
     "siv_conv1x1_fwd": [_f, _f, _f, _f, _l, _i, _i, _f],

@@ -230,6 +230,27 @@ class HipBackend:
                    "siv_bnact_conv3d_k3_to1_fwd")
         return y
 
+    def bnact_conv_to1_dgrad(self, dy, w, x, mean, var, gamma, beta, eps: float, slope: float,
+                             want_affine: bool, dgamma_out=None, dbeta_out=None):
+        """Gradient of the raw tensor ``x`` (and of gamma / beta: returned, or ADDED into the given buffers)."""
+        self._check_dev(dy, w, x, mean, var, gamma, beta, dgamma_out, dbeta_out)
+        dy, w, x = cl(dy), cl(w), cl(x)
+        N, C, D, H, W = x.shape
+        dx = like(x)
+        acc = 0
+        if want_affine and dgamma_out is not None:
+            assert dbeta_out is not None and dgamma_out.is_contiguous() and dbeta_out.is_contiguous()
+            dgamma, dbeta, acc = dgamma_out, dbeta_out, 1
+        else:
+            dgamma = torch.empty(C, device=x.device, dtype=torch.float32) if want_affine else None
+            dbeta = torch.empty(C, device=x.device, dtype=torch.float32) if want_affine else None
+        ws, wsb = self._workspace(x)
+        _lib.check(self.lib.siv_bnact_conv3d_k3_to1_dgrad(_p(dy), _p(w), _p(x), _p(mean), _p(var), _p(gamma),
+                                                          _p(beta), eps, slope, _p(dx), _p(dgamma), _p(dbeta), acc,
+                                                          N, D, H, W, C, ws, wsb, self._stream(x)),
+                   "siv_bnact_conv3d_k3_to1_dgrad")
+        return dx, dgamma, dbeta
+
     def bnact_conv_to1_wgrad(self, x, mean, var, gamma, beta, eps: float, slope: float, dy,
                              want_bias: bool = False, dw_out=None, db_out=None):
         self._check_dev(x, mean, var, gamma, beta, dy, dw_out, db_out)

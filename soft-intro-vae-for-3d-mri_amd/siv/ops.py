@@ -294,8 +294,8 @@ def conv_bn_act(x, conv, bn, slope: float, ups: int = 1, pool: int = 1, residual
 class _BnActConvTo1(Function):
     """BatchNorm3d -> LeakyReLU -> Conv3d(C, 1, 3, 1, 1) with the first two applied while the convolution
     loads its operand: the activated C-channel tensor is neither written nor read, in forward or in the
-    weight gradient.  Backward = input gradient of the convolution, its weight gradient (same prologue),
-    then BatchNorm's own backward."""
+    weight gradient.  Backward = the weight gradient (same prologue) and one fused call for the convolution's
+    input gradient and BatchNorm's own backward."""
 
     @staticmethod
     def forward(ctx, y, gamma, beta, w, bias, bn, slope, train, stats):
@@ -328,14 +328,12 @@ class _BnActConvTo1(Function):
                 if not ctx.needs_input_grad[3]:
                     dw = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            da = B.conv3d_k3_dgrad(dout, w, 1)             # gradient of the activation that was never stored
+            # the gradient of the activation (never stored either) is recomputed inside both passes
             want_aff = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and g_buf is not None and b_buf is not None:
-                dy, _, _, _ = B.bn_act_bwd(da, y, mean, var, gamma, beta, None, None, 0.0, slope, 1, eps, True,
-                                           False, g_buf, b_buf)
+                dy, _, _ = B.bnact_conv_to1_dgrad(dout, w, y, mean, var, gamma, beta, eps, slope, True, g_buf, b_buf)
             else:
-                dy, dg, db, _ = B.bn_act_bwd(da, y, mean, var, gamma, beta, None, None, 0.0, slope, 1, eps,
-                                             want_aff, False)
+                dy, dg, db = B.bnact_conv_to1_dgrad(dout, w, y, mean, var, gamma, beta, eps, slope, want_aff)
             if not ctx.needs_input_grad[0]:
                 dy = None
         return (dy, dg if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None, dw, dcb,

@@ -521,6 +521,20 @@ def test_bnact_conv_to1_matches_separate_ops(B, dims, n):
     acc = dev(torch.ones_like(w)).contiguous(memory_format=torch.channels_last_3d)
     B.bnact_conv_to1_wgrad(*args, dev(dy), False, acc, None)
     check(acc, 1 + wd.grad.float(), "fused weight gradient, accumulated")
+    # input gradient of the convolution + BatchNorm backward in one call: dx, dgamma, dbeta
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    x2 = x.double().requires_grad_(True)
+    m2, v2 = x2.mean(dim=(0, 2, 3, 4), keepdim=True), x2.var(dim=(0, 2, 3, 4), unbiased=False, keepdim=True)
+    F.conv3d(F.leaky_relu((x2 - m2) / torch.sqrt(v2 + eps) * gd.view(1, -1, 1, 1, 1) + bd.view(1, -1, 1, 1, 1), slope),
+             w.double(), None, padding=1).backward(dy.double())
+    dx, dgm, dbt = B.bnact_conv_to1_dgrad(dev(dy), dev(w), *args, True)
+    check(dx, x2.grad.float(), "fused input gradient")
+    check(dgm, gd.grad.float(), "fused dgamma")
+    check(dbt, bd.grad.float(), "fused dbeta")
+    ag, ab = torch.ones(C, device="cuda"), torch.full((C,), 2.0, device="cuda")
+    B.bnact_conv_to1_dgrad(dev(dy), dev(w), *args, True, ag, ab)
+    check(ag, 1 + gd.grad.float(), "dgamma, accumulated")
+    check(ab, 2 + bd.grad.float(), "dbeta, accumulated")
 
     # the autograd operator against the unfused operators: same statistics, same parameters
     class _Bn(torch.nn.BatchNorm3d):
