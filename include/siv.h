@@ -121,6 +121,28 @@ int siv_conv3d_k3_dgrad_up(const float* dy, const float* w, float* dx, int N, in
 int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, float* dbias,
                         int N, int D, int H, int W, int Cin, int Cout, int ups, int accumulate,
                         void* ws, size_t ws_bytes, siv_stream_t stream);
+/* The encoder stem as one operator: nn.Conv3d(1, Cout, 3, 1, 1) -> nn.BatchNorm3d -> nn.LeakyReLU ->
+ * nn.Dropout (models/models.py:91-96, the stem of ResNetEncoder).  The convolution output costs 27
+ * multiply-adds per element from the single-channel input, so it is never stored: the statistics
+ * pass, the apply pass and both passes of the backward recompute it on the matrix pipe.
+ * _fwd: x[N][D][H][W], w[Cout][27], out[N][D][H][W][Cout]; keep (uint8, layout of out) / p as in
+ * siv_bn_act_fwd; train != 0: batch statistics are computed, written to mean / var[Cout] and folded
+ * into the running statistics (as siv_bn_stats); train == 0: mean / var are inputs.
+ * _bwd: dout[N][D][H][W][Cout] -> dy = gradient of the (never stored) convolution output, which is
+ * what siv_conv3d_k3_wgrad / _dgrad of the stem take; dgamma / dbeta written or (accumulate = 1) added.
+ * Cout % 4 == 0, Cout <= 64 (siv_conv1_bnact_supported). */
+int siv_conv1_bnact_supported(int Cout);
+int siv_conv1_bnact_fwd(const float* x, const float* w, const float* bias, const float* gamma,
+                        const float* beta, const uint8_t* keep, float p, float slope, float eps, int train,
+                        float* mean, float* var, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float momentum, float* out,
+                        int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, siv_stream_t stream);
+int siv_conv1_bnact_bwd(const float* dout, const float* x, const float* w, const float* bias,
+                        const float* mean, const float* var, const float* gamma, const float* beta,
+                        const uint8_t* keep, float p, float slope, float eps, float* dy, float* dgamma,
+                        float* dbeta, int accumulate, int N, int D, int H, int W, int Cout,
+                        void* ws, size_t ws_bytes, siv_stream_t stream);
+
 /* BatchNorm3d + LeakyReLU folded into the Cin -> 1 convolution behind them: the decoder's last block
  * ends in conv -> BatchNorm -> LeakyReLU and feeds the output layer nn.Conv3d(in_ch, 1, 3, 1, 1)
  * (models/models.py:76-78 and :137).  x is the block's RAW convolution output [N][D][H][W][Cin]; the

@@ -239,8 +239,9 @@ __global__ __launch_bounds__(256, 3) void tail_bn_bwd_k(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = qok ? 4 * q + j : 0;
+        // the association of bn_act.hip: a = gamma / sqrt(var + eps), xhat = (y - mean) * (1 / sqrt(var + eps))
         ci[j] = 1.0f / sqrtf(bn.var[c] + bn.eps);
-        ca[j] = bn.gamma[c] * ci[j];
+        ca[j] = bn.gamma[c] / sqrtf(bn.var[c] + bn.eps);
         cm[j] = bn.mean[c];
         cb[j] = bn.beta[c] - cm[j] * ca[j];
         k1[j] = STAGE == 1 ? sums[c] * invM : 0.f;
@@ -310,6 +311,167 @@ __global__ __launch_bounds__(256, 3) void tail_bn_bwd_k(const float* __restrict_
         }
     }
     if (STAGE == 0) {           // part[block][2][C]: the four lanes of a channel quad, then the four waves
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int o = 16; o < 64; o <<= 1) {
+                s1[j] += __shfl_xor(s1[j], o, 64);
+                s2[j] += __shfl_xor(s2[j], o, 64);
+            }
+        __syncthreads();
+        float* red = hal[0];                   // [4 waves][2][64 channels]
+        if (lane < 16) {
+            *reinterpret_cast<float4*>(red + (wv * 2 + 0) * 64 + 4 * q) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+            *reinterpret_cast<float4*>(red + (wv * 2 + 1) * 64 + 4 * q) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int k = threadIdx.x >> 6, c = threadIdx.x & 63;
+            if (c < C)
+                part[((long)blockIdx.x * 2 + k) * C + c] =
+                    (red[(0 * 2 + k) * 64 + c] + red[(1 * 2 + k) * 64 + c]) +
+                    (red[(2 * 2 + k) * 64 + c] + red[(3 * 2 + k) * 64 + c]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// The encoder stem Conv3d(1, C, 3) -> BatchNorm -> LeakyReLU -> Dropout without its convolution output
+// ever reaching memory: y[v][c] = bias[c] + sum_tap a[v + tap - 1] * w[c][tap] costs 27 multiply-adds
+// per element from a single-channel halo brick, so every pass that needs y recomputes it on the matrix
+// pipe (the tiling of one_to_c_mfma_k) instead of one kernel writing it (157 MB per volume) and up to
+// four reading it:
+//   SM_STATS: per-block sums of (y - bias) and its square                  -> part[block][2][C]
+//   SM_APPLY: out = dropout(act(y * a + b))                                 (forward)
+//   SM_BSUM:  dz = dout * keep/(1-p) * act'(z); per-block sums of dz, dz * xhat -> part[block][2][C]
+//   SM_BAPP:  dy = a * (dz - sum(dz)/M - xhat * sum(dz * xhat)/M)            (gradient of y, for the
+//             stem's weight gradient)
+// Recomputed values are bit-identical in every pass (same instruction sequence).
+// ---------------------------------------------------------------------------------
+enum { SM_STATS = 0, SM_APPLY = 1, SM_BSUM = 2, SM_BAPP = 3 };
+
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
+                                                    const float* __restrict__ w,
+                                                    const float* __restrict__ bias, BnPrologue bn,
+                                                    const uint8_t* __restrict__ keep, float p,
+                                                    const float* __restrict__ dout,
+                                                    const float* __restrict__ sums, float invM,
+                                                    float* __restrict__ part, float* __restrict__ out,
+                                                    int N, int D, int H, int W, int C, int nbd, int nbh,
+                                                    int nbw, int bricks_per_block, int nbricks) {
+    __shared__ float hal[2][TH_V];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = lane & 15, kk = lane >> 4;
+    const bool qok = 4 * q < C;
+    float wb[7][4];
+    int toff[7];
+#pragma unroll
+    for (int st = 0; st < 7; ++st) {
+        const int t = 4 * st + kk;
+        toff[st] = t < 27 ? ((t / 9) * TH_H + (t / 3) % 3) * TH_W + t % 3 : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wb[st][j] = (t < 27 && qok) ? w[(4 * q + j) * 27 + t] : 0.f;
+    }
+    float bq[4], ca[4], cb[4], cm[4], ci[4], k1[4], k2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = qok ? 4 * q + j : 0;
+        bq[j] = (bias && qok) ? bias[c] : 0.f;
+        if (MODE != SM_STATS) {
+            // the association of bn_act.hip: a = gamma / sqrt(var + eps), xhat = (y - mean) * (1 / sqrt(var + eps))
+            ci[j] = 1.0f / sqrtf(bn.var[c] + bn.eps);
+            ca[j] = bn.gamma[c] / sqrtf(bn.var[c] + bn.eps);
+            cm[j] = bn.mean[c];
+            cb[j] = bn.beta[c] - cm[j] * ca[j];
+        }
+        k1[j] = MODE == SM_BAPP ? sums[c] * invM : 0.f;
+        k2[j] = MODE == SM_BAPP ? sums[C + c] * invM : 0.f;
+    }
+    const float dscale = 1.0f / (1.0f - p);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int b0 = blockIdx.x * bricks_per_block;
+    const int b1 = b0 + bricks_per_block < nbricks ? b0 + bricks_per_block : nbricks;
+    int buf = 0;
+    for (int br = b0; br < b1; ++br, buf ^= 1) {
+        int n, z0, y0, x0;
+        brick_coords(br, nbd, nbh, nbw, n, z0, y0, x0);
+        load_halo1(a, hal[buf], n, z0, y0, x0, D, H, W);
+        __syncthreads();
+        const int gz = z0 + wv;
+        if (gz >= D) continue;
+        const long base = ((((long)n * D + gz) * H + y0) * W + x0) * C + 4 * q;
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {                // 16 voxels = brick rows 2 tl, 2 tl + 1
+            bool ok[4];
+            long off[4];
+            float4 gv[4];
+            uint32_t kv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = 4 * kk + e;
+                const int dyy = 2 * tl + (m >> 3), dx = m & 7;
+                ok[e] = qok && y0 + dyy < H && x0 + dx < W;
+                off[e] = ok[e] ? base + ((long)dyy * W + dx) * C : 0;
+                // what the pass reads goes out first (clamped, unconditional) and has the products to arrive
+                if (MODE == SM_BSUM || MODE == SM_BAPP) gv[e] = *reinterpret_cast<const float4*>(dout + off[e]);
+                if (MODE != SM_STATS && keep) kv[e] = *reinterpret_cast<const uint32_t*>(keep + off[e]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float* hp = hal[buf] + (wv * TH_H + 2 * tl + (q >> 3)) * TH_W + (q & 7);
+            float av[7];
+#pragma unroll
+            for (int st = 0; st < 7; ++st) av[st] = hp[toff[st]];
+            f32x4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 7; ++st)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], wb[st][j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gg[4] = {gv[e].x, gv[e].y, gv[e].z, gv[e].w};
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[j][e];                  // bias-free convolution output
+                    if (MODE == SM_STATS) {
+                        if (ok[e]) {
+                            s1[j] += v;
+                            s2[j] = fmaf(v, v, s2[j]);
+                        }
+                        continue;
+                    }
+                    const float yv = v + bq[j];
+                    const float z = fmaf(yv, ca[j], cb[j]);
+                    const bool kept = !keep || ((kv[e] >> (8 * j)) & 0xffu) != 0;
+                    if (MODE == SM_APPLY) {
+                        float r = z > 0.f ? z : z * bn.slope;
+                        if (keep) r = kept ? r * dscale : 0.f;
+                        o[j] = r;
+                        continue;
+                    }
+                    float g = gg[j];
+                    if (keep) g = kept ? g * dscale : 0.f;
+                    const float dz = g * (z > 0.f ? 1.f : bn.slope);
+                    const float xh = (yv - cm[j]) * ci[j];
+                    if (MODE == SM_BSUM) {
+                        if (ok[e]) {
+                            s1[j] += dz;
+                            s2[j] = fmaf(dz, xh, s2[j]);
+                        }
+                    } else {
+                        o[j] = ca[j] * (dz - k1[j] - xh * k2[j]);
+                    }
+                }
+                if ((MODE == SM_APPLY || MODE == SM_BAPP) && ok[e])
+                    *reinterpret_cast<float4*>(out + off[e]) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    if (MODE == SM_STATS || MODE == SM_BSUM) {   // part[block][2][C]: the lanes of a channel quad, then the waves
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1116,6 +1278,81 @@ int k3_thin_bn_dgrad_launch(const float* g1, const float* w, const float* x, con
     tail_bn_bwd_k<1><<<(unsigned)nblk, 256, 0, s>>>(g1, w, x, bn, sums, invM, nullptr, dx, N, D, H, W, Cin, nbd, nbh,
                                                    nbw, bpb, (int)nbricks);
     SIV_CHECK_LAUNCH("bnact_conv3d_k3_to1(dgrad, apply)");
+    return SIV_OK;
+}
+
+int bn_finalize_launch(const float* shift, const float* part, int nblk, long M, int C, float* mean,
+                       float* var, float* running_mean, float* running_var, int64_t* nbt,
+                       float momentum, hipStream_t s);
+
+struct StemGrid {
+    int nbd, nbh, nbw, bpb;
+    long nbricks, nblk;
+    size_t part_bytes;
+};
+static int stem_grid(const char* what, int N, int D, int H, int W, int C, size_t ws_bytes, StemGrid& g) {
+    if (C % 4 != 0 || C > 64) {
+        set_error("%s: needs Cout %% 4 == 0 and Cout <= 64 (got %d)", what, C);
+        return SIV_EINVAL;
+    }
+    g.nbd = (D + TB_D - 1) / TB_D, g.nbh = (H + TB_H - 1) / TB_H, g.nbw = (W + TB_W - 1) / TB_W;
+    thin_1c_grid(N, D, H, W, g.nbricks, g.bpb);
+    if (g.nbricks > 0x7fffffffL || (long)N * D * H * W * C > 0x7fffffffffL) {
+        set_error("%s: volume too large", what);
+        return SIV_EINVAL;
+    }
+    g.nblk = cdiv(g.nbricks, g.bpb);
+    g.part_bytes = align256((size_t)g.nblk * 2 * C * sizeof(float));
+    SIV_CHECK_WS(g.part_bytes + (size_t)2 * C * sizeof(float), ws_bytes, what);
+    return SIV_OK;
+}
+
+// Forward of Conv3d(1, C, 3) -> BatchNorm -> LeakyReLU -> Dropout.  train: batch statistics are computed
+// (mean, var written, running statistics updated); otherwise mean / var are used as given.
+int stem_bnact_fwd_launch(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                          const uint8_t* keep, float p, float slope, float eps, int train, float* mean, float* var,
+                          float* running_mean, float* running_var, int64_t* nbt, float momentum, float* out, int N,
+                          int D, int H, int W, int C, void* ws, size_t ws_bytes, hipStream_t s) {
+    StemGrid g;
+    int rc = stem_grid("conv1_bnact_fwd", N, D, H, W, C, ws_bytes, g);
+    if (rc) return rc;
+    const BnPrologue bn{mean, var, gamma, beta, eps, slope};
+    if (train) {
+        float* part = (float*)ws;
+        stem_bn_k<SM_STATS><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, nullptr, 0.f, nullptr, nullptr, 0.f, part,
+                                                            nullptr, N, D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb,
+                                                            (int)g.nbricks);
+        SIV_CHECK_LAUNCH("conv1_bnact_fwd(statistics)");
+        rc = bn_finalize_launch(bias, part, (int)g.nblk, (long)N * D * H * W, C, mean, var, running_mean, running_var,
+                                nbt, momentum, s);
+        if (rc) return rc;
+    }
+    stem_bn_k<SM_APPLY><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, p, nullptr, nullptr, 0.f, nullptr, out, N,
+                                                        D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks);
+    SIV_CHECK_LAUNCH("conv1_bnact_fwd(apply)");
+    return SIV_OK;
+}
+
+// Backward of the same down to the convolution output: dy (gradient of the never-stored y), dgamma, dbeta.
+int stem_bnact_bwd_launch(const float* dout, const float* x, const float* w, const float* bias, const float* mean,
+                          const float* var, const float* gamma, const float* beta, const uint8_t* keep, float p,
+                          float slope, float eps, float* dy, float* dgamma, float* dbeta, int accumulate, int N,
+                          int D, int H, int W, int C, void* ws, size_t ws_bytes, hipStream_t s) {
+    StemGrid g;
+    int rc = stem_grid("conv1_bnact_bwd", N, D, H, W, C, ws_bytes, g);
+    if (rc) return rc;
+    const BnPrologue bn{mean, var, gamma, beta, eps, slope};
+    float* part = (float*)ws;
+    float* sums = (float*)((char*)ws + g.part_bytes);
+    const float invM = 1.0f / (float)((long)N * D * H * W);
+    stem_bn_k<SM_BSUM><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, p, dout, nullptr, invM, part, nullptr, N, D,
+                                                       H, W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks);
+    SIV_CHECK_LAUNCH("conv1_bnact_bwd(sums)");
+    rc = bn_bwd_finalize_launch(part, (int)g.nblk, C, sums, dgamma, dbeta, accumulate, s);
+    if (rc) return rc;
+    stem_bn_k<SM_BAPP><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, p, dout, sums, invM, nullptr, dy, N, D, H,
+                                                       W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks);
+    SIV_CHECK_LAUNCH("conv1_bnact_bwd(apply)");
     return SIV_OK;
 }
 

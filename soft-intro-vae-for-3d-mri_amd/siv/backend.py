@@ -211,6 +211,55 @@ class HipBackend:
                                                 ws, wsb, self._stream(dy)), "siv_conv3d_k3_wgrad")
         return dw, db
 
+    # ---- the encoder stem Conv3d(1, C) -> BatchNorm -> LeakyReLU -> Dropout as one operator ------------
+    def conv1_bnact_supported(self, x, w) -> bool:
+        return bool(x.is_cuda and x.dim() == 5 and x.shape[1] == 1 and
+                    self.lib.siv_conv1_bnact_supported(int(w.shape[0])))
+
+    def conv1_bnact_fwd(self, x, w, bias, gamma, beta, keep, p, slope, eps, train: bool, running_mean,
+                        running_var, nbt, momentum: float):
+        """Returns (out, mean, var); in evaluation mode mean / var are the running statistics."""
+        self._check_dev(x, w, bias, gamma, beta, keep, running_mean, running_var, nbt)
+        x, w = x.contiguous(), cl(w)
+        keep = cl(keep) if keep is not None else None
+        N, _, D, H, W = x.shape
+        C = w.shape[0]
+        out = empty_cl((N, C, D, H, W), x)
+        if train:
+            mean = torch.empty(C, device=x.device, dtype=torch.float32)
+            var = torch.empty(C, device=x.device, dtype=torch.float32)
+            rm, rv, nb = running_mean, running_var, nbt
+        else:
+            mean, var, rm, rv, nb = running_mean, running_var, None, None, None
+        ws, wsb = self._workspace(x)
+        _lib.check(self.lib.siv_conv1_bnact_fwd(_p(x), _p(w), _p(bias), _p(gamma), _p(beta), _p(keep), float(p),
+                                                float(slope), float(eps), int(train), _p(mean), _p(var), _p(rm),
+                                                _p(rv), _p(nb), float(momentum), _p(out), N, D, H, W, C, ws, wsb,
+                                                self._stream(x)), "siv_conv1_bnact_fwd")
+        return out, mean, var
+
+    def conv1_bnact_bwd(self, dout, x, w, bias, mean, var, gamma, beta, keep, p, slope, eps,
+                        want_affine: bool, dgamma_out=None, dbeta_out=None):
+        """Gradient of the convolution output (and of gamma / beta: returned, or ADDED into the buffers)."""
+        self._check_dev(dout, x, w, bias, mean, var, gamma, beta, keep, dgamma_out, dbeta_out)
+        dout, x, w = cl(dout), x.contiguous(), cl(w)
+        keep = cl(keep) if keep is not None else None
+        N, C, D, H, W = dout.shape
+        dy = like(dout)
+        acc = 0
+        if want_affine and dgamma_out is not None:
+            assert dbeta_out is not None and dgamma_out.is_contiguous() and dbeta_out.is_contiguous()
+            dgamma, dbeta, acc = dgamma_out, dbeta_out, 1
+        else:
+            dgamma = torch.empty(C, device=x.device, dtype=torch.float32) if want_affine else None
+            dbeta = torch.empty(C, device=x.device, dtype=torch.float32) if want_affine else None
+        ws, wsb = self._workspace(dout)
+        _lib.check(self.lib.siv_conv1_bnact_bwd(_p(dout), _p(x), _p(w), _p(bias), _p(mean), _p(var), _p(gamma),
+                                                _p(beta), _p(keep), float(p), float(slope), float(eps), _p(dy),
+                                                _p(dgamma), _p(dbeta), acc, N, D, H, W, C, ws, wsb,
+                                                self._stream(dout)), "siv_conv1_bnact_bwd")
+        return dy, dgamma, dbeta
+
     # ---- BatchNorm + LeakyReLU folded into the Cin -> 1 convolution behind them ---------------------
     def bnact_conv_to1_supported(self, x) -> bool:
         """True when ``bnact_conv_to1_fwd`` has a kernel for the raw convolution output ``x``."""

@@ -155,7 +155,10 @@ class ResNetEncoder(nn.Module):
         v = self.variant
         conv, bn = self.blocks[0][0], self.blocks[0][1]
         keep = _keep((x.shape[0], conv.out_channels) + tuple(x.shape[2:]), v.p_enc_stem, self.training, x.device)
-        h = ops.conv_bn_act(x, conv, bn, v.slope, keep=keep, p=v.p_enc_stem, train=self.training)
+        if ops.conv1_bn_act_supported(x, conv):      # the stem's convolution output is never stored
+            h = ops.conv1_bn_act(x, conv, bn, v.slope, keep=keep, p=v.p_enc_stem, train=self.training)
+        else:
+            h = ops.conv_bn_act(x, conv, bn, v.slope, keep=keep, p=v.p_enc_stem, train=self.training)
         for blk in list(self.blocks)[1:]:
             h = blk[0](h)
         return h

@@ -291,6 +291,66 @@ def conv_bn_act(x, conv, bn, slope: float, ups: int = 1, pool: int = 1, residual
     return bn_act(y, bn, slope, pool, residual, keep, p, False)
 
 
+class _Conv1BnAct(Function):
+    """Conv3d(1, C, 3, 1, 1) -> BatchNorm3d -> LeakyReLU -> Dropout (the encoder stem) with the convolution
+    output recomputed by every pass instead of stored; backward hands the gradient of that output to the
+    ordinary weight / input gradient kernels of the convolution."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta, keep, bn, p, slope, train):
+        B = get_backend()
+        out, mean, var = B.conv1_bnact_fwd(x, w, bias, gamma, beta, keep, p, slope, bn.eps, train,
+                                           bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                           BN_MOMENTUM if bn.momentum is None else bn.momentum)
+        ctx.save_for_backward(x, w, bias, mean, var, gamma, beta, keep)
+        ctx.cfg = (p, slope, bn.eps, train)
+        ctx.bufs = (_grad_buf(w), _grad_buf(bias), _grad_buf(gamma), _grad_buf(beta))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, bias, mean, var, gamma, beta, keep = ctx.saved_tensors
+        p, slope, eps, train = ctx.cfg
+        w_buf, cb_buf, g_buf, b_buf = ctx.bufs
+        if not train:
+            raise NotImplementedError("backward through evaluation-mode BatchNorm is not part of the "
+                                      "training path (the reference validates under torch.no_grad())")
+        B = get_backend()
+        dx = dw = dcb = dg = db = None
+        want_aff = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        if ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and g_buf is not None and b_buf is not None:
+            dy, _, _ = B.conv1_bnact_bwd(dout, x, w, bias, mean, var, gamma, beta, keep, p, slope, eps, True,
+                                         g_buf, b_buf)
+        else:
+            dy, dg, db = B.conv1_bnact_bwd(dout, x, w, bias, mean, var, gamma, beta, keep, p, slope, eps, want_aff)
+        want_cb = bias is not None and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_cb:
+            direct = ctx.needs_input_grad[1] and w_buf is not None and (not want_cb or cb_buf is not None)
+            if direct:
+                _wgrad_on_side_stream(B, x, dy, _side_ready(B, dy),
+                                      lambda: B.conv3d_k3_wgrad(x, dy, 1, want_cb, w_buf, cb_buf))
+            else:
+                dw, dcb = B.conv3d_k3_wgrad(x, dy, 1, want_cb)
+                if not ctx.needs_input_grad[1]:
+                    dw = None
+        if ctx.needs_input_grad[0]:
+            dx = B.conv3d_k3_dgrad(dy, w, 1)
+        return (dx, dw, dcb, dg if ctx.needs_input_grad[3] else None, db if ctx.needs_input_grad[4] else None,
+                None, None, None, None, None)
+
+
+def conv1_bn_act_supported(x, conv) -> bool:
+    B = get_backend()
+    return (hasattr(B, "conv1_bnact_supported") and conv.in_channels == 1 and
+            B.conv1_bnact_supported(x, conv.weight))
+
+
+def conv1_bn_act(x, conv, bn, slope: float, keep=None, p: float = 0.0, train: bool = True):
+    """``dropout(LeakyReLU(bn(conv(x))))`` for a single-channel input as one operator (see
+    ``conv1_bn_act_supported``); the fallback is ``conv_bn_act``."""
+    return _Conv1BnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, keep, bn, p, slope, train)
+
+
 class _BnActConvTo1(Function):
     """BatchNorm3d -> LeakyReLU -> Conv3d(C, 1, 3, 1, 1) with the first two applied while the convolution
     loads its operand: the activated C-channel tensor is neither written nor read, in forward or in the

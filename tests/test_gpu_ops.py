@@ -485,6 +485,79 @@ def test_conv_fwd_with_bn_statistics(B, cin, cout, dims, n, ups, path, use_bias)
     assert int(nbt) == 5
 
 
+@pytest.mark.parametrize("C,dims,n,p", [(64, (9, 10, 11), 2, 0.2), (16, (16, 24, 20), 1, 0.0), (64, (8, 12, 8), 3, 0.35),
+                                        (12, (6, 7, 5), 2, 0.5)])
+def test_conv1_bnact_matches_separate_ops(B, C, dims, n, p):
+    """The encoder stem Conv3d(1, C) -> BatchNorm -> LeakyReLU -> Dropout (models/models.py:91-96) as one
+    operator that never stores the convolution output: forward, batch / running statistics and the
+    backward down to the convolution output against float64 autograd of the composition; the autograd
+    operator (incl. the stem's weight, bias and input gradients) against the unfused operators."""
+    import siv.ops as ops
+    gen = torch.Generator().manual_seed(C + dims[0] + n)
+    D, H, W = dims
+    slope, eps = 0.2, 1e-5
+    x = torch.rand(n, 1, D, H, W, generator=gen)
+    w, b = rnd(gen, C, 1, 3, 3, 3, scale=0.4), rnd(gen, C) * 2
+    gamma, beta = 1 + 0.3 * rnd(gen, C), 0.2 * rnd(gen, C)
+    keep = (torch.rand(n, C, D, H, W, generator=gen) >= p).to(torch.uint8) if p > 0 else None
+    dout = rnd(gen, n, C, D, H, W)
+    rm0, rv0 = rnd(gen, C), torch.rand(C, generator=gen) + 0.5
+    # float64 reference
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    gd, btd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yd = F.conv3d(x.double(), wd, bd, padding=1)
+    yd.retain_grad()
+    mu = yd.mean(dim=(0, 2, 3, 4), keepdim=True)
+    vr = yd.var(dim=(0, 2, 3, 4), unbiased=False, keepdim=True)
+    act = F.leaky_relu((yd - mu) / torch.sqrt(vr + eps) * gd.view(1, -1, 1, 1, 1) + btd.view(1, -1, 1, 1, 1), slope)
+    ref = act * keep.double() / (1 - p) if keep is not None else act
+    ref.backward(dout.double())
+    rm, rv, nbt = dev(rm0.clone()), dev(rv0.clone()), torch.tensor(7, device="cuda")
+    assert B.conv1_bnact_supported(dev(x), dev(w))
+    out, mean, var = B.conv1_bnact_fwd(dev(x), dev(w), dev(b), dev(gamma), dev(beta), dev(keep), p, slope, eps, True,
+                                       rm, rv, nbt, 0.1)
+    check(out, ref.detach().float(), "fused forward")
+    check(mean, mu.flatten().float(), "batch mean")
+    check(var, vr.flatten().float(), "batch variance")
+    m = yd.numel() // C
+    check(rm, (0.9 * rm0.double() + 0.1 * mu.flatten()).float(), "running mean")
+    check(rv, (0.9 * rv0.double() + 0.1 * vr.flatten() * m / (m - 1)).float(), "running variance")
+    assert int(nbt) == 8
+    dy, dg, db = B.conv1_bnact_bwd(dev(dout), dev(x), dev(w), dev(b), mean, var, dev(gamma), dev(beta), dev(keep), p,
+                                   slope, eps, True)
+    check(dy, yd.grad.float(), "gradient of the convolution output", max_outliers=2)
+    check(dg, gd.grad.float(), "dgamma")
+    check(db, btd.grad.float(), "dbeta")
+    # evaluation mode: running statistics, nothing updated
+    oe, _, _ = B.conv1_bnact_fwd(dev(x), dev(w), dev(b), dev(gamma), dev(beta), None, 0.0, slope, eps, False,
+                                 dev(rm0), dev(rv0), None, 0.1)
+    ye = F.leaky_relu((yd.detach() - rm0.double().view(1, -1, 1, 1, 1)) / torch.sqrt(rv0.double().view(1, -1, 1, 1, 1) + eps)
+                      * gamma.double().view(1, -1, 1, 1, 1) + beta.double().view(1, -1, 1, 1, 1), slope)
+    check(oe, ye.float(), "evaluation-mode forward")
+
+    # the autograd operator against the unfused operators
+    outs = []
+    for fused in (True, False):
+        bn = torch.nn.BatchNorm3d(C).to("cuda").train()
+        conv = torch.nn.Conv3d(1, C, 3, 1, 1).to("cuda")
+        with torch.no_grad():
+            bn.weight.copy_(dev(gamma)); bn.bias.copy_(dev(beta))
+            conv.weight.copy_(dev(w)); conv.bias.copy_(dev(b))
+        xg = dev(x).requires_grad_(True)
+        fn = ops.conv1_bn_act if fused else ops.conv_bn_act
+        o = fn(xg, conv, bn, slope, keep=dev(keep), p=p, train=True)
+        o.backward(dev(dout))
+        outs.append((o.detach(), xg.grad, conv.weight.grad, conv.bias.grad, bn.weight.grad, bn.bias.grad,
+                     bn.running_mean.clone(), bn.running_var.clone()))
+    for a_, b_, what in zip(outs[0], outs[1], ("out", "dx", "dw", "dbias", "dgamma", "dbeta", "running mean",
+                                               "running var")):
+        if what == "dbias":          # BatchNorm cancels the convolution bias: both are rounding noise around zero
+            assert float(a_.abs().max()) <= 1e-3 * float(outs[0][2].abs().max()) + 1e-6
+            continue
+        check(a_, b_, "operator: " + what, tol=5e-5, max_outliers=2)
+    check(outs[0][2], wd.grad.float(), "dw against float64")
+
+
 @pytest.mark.parametrize("dims,n", [((16, 24, 32), 2), ((19, 44, 36), 1), ((16, 12, 16), 3)])
 def test_bnact_conv_to1_matches_separate_ops(B, dims, n):
     """BatchNorm + LeakyReLU folded into the 64 -> 1 output convolution (models/models.py:76-78,137):
