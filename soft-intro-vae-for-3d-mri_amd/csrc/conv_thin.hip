@@ -39,6 +39,32 @@ __device__ __forceinline__ void load_halo1(const float* __restrict__ a, float* h
     }
 }
 
+// The same in two halves for kernels that walk several bricks: the halo of brick b + 1 is fetched into
+// registers while brick b is being worked on and put into LDS at the top of the next round, so its
+// global-memory latency is not paid between two barriers.
+constexpr int TH_PER_THREAD = (TH_V + 255) / 256;      // 3
+__device__ __forceinline__ void halo1_fetch(const float* __restrict__ a, float (&hr)[TH_PER_THREAD], int br,
+                                            int nbd, int nbh, int nbw, int D, int H, int W) {
+    int n, z0, y0, x0;
+    brick_coords(br, nbd, nbh, nbw, n, z0, y0, x0);
+#pragma unroll
+    for (int i = 0; i < TH_PER_THREAD; ++i) {
+        const int hv = threadIdx.x + 256 * i;
+        const int hx = hv % TH_W, hy = (hv / TH_W) % TH_H, hz = hv / (TH_W * TH_H);
+        const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const bool ok = hv < TH_V && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const float v = a[ok ? (((long)n * D + gz) * H + gy) * W + gx : 0];     // clamped, unconditional
+        hr[i] = ok ? v : 0.f;
+    }
+}
+__device__ __forceinline__ void halo1_put(float* hal, const float (&hr)[TH_PER_THREAD]) {
+#pragma unroll
+    for (int i = 0; i < TH_PER_THREAD; ++i) {
+        const int hv = threadIdx.x + 256 * i;
+        if (hv < TH_V) hal[hv] = hr[i];
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // one_to_c.  Thread = (voxel lane, channel quad); the quad's 27x4 weights live in registers.
 // ---------------------------------------------------------------------------------
@@ -109,7 +135,7 @@ __global__ __launch_bounds__(256) void one_to_c_k(const float* __restrict__ a,
 // ---------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256, 4) void one_to_c_mfma_k(const float* __restrict__ a,
+__global__ __launch_bounds__(256, 3) void one_to_c_mfma_k(const float* __restrict__ a,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ bias,
                                                           float* __restrict__ out, int N, int D, int H,
@@ -139,12 +165,16 @@ __global__ __launch_bounds__(256, 4) void one_to_c_mfma_k(const float* __restric
     const int b0 = blockIdx.x * bricks_per_block;
     const int b1 = b0 + bricks_per_block < nbricks ? b0 + bricks_per_block : nbricks;
     int buf = 0;
+    float hr[TH_PER_THREAD];
+    if (b0 < b1) halo1_fetch(a, hr, b0, nbd, nbh, nbw, D, H, W);
     for (int br = b0; br < b1; ++br, buf ^= 1) {
         int n, z0, y0, x0;
         brick_coords(br, nbd, nbh, nbw, n, z0, y0, x0);
         // two halo images: a wave still working on the previous brick reads the other one
-        load_halo1(a, hal[buf], n, z0, y0, x0, D, H, W);
+        halo1_put(hal[buf], hr);
         __syncthreads();
+        if (br + 1 < b1) halo1_fetch(a, hr, br + 1, nbd, nbh, nbw, D, H, W);
+        __builtin_amdgcn_sched_barrier(0);
         const int gz = z0 + wv;
         if (gz >= D) continue;
         float* op = out + ((((long)n * D + gz) * H + y0) * W + x0) * C + 4 * q;
@@ -251,11 +281,15 @@ __global__ __launch_bounds__(256, 3) void tail_bn_bwd_k(const float* __restrict_
     const int b0 = blockIdx.x * bricks_per_block;
     const int b1 = b0 + bricks_per_block < nbricks ? b0 + bricks_per_block : nbricks;
     int buf = 0;
+    float hr[TH_PER_THREAD];
+    if (b0 < b1) halo1_fetch(g1, hr, b0, nbd, nbh, nbw, D, H, W);
     for (int br = b0; br < b1; ++br, buf ^= 1) {
         int n, z0, y0, x0;
         brick_coords(br, nbd, nbh, nbw, n, z0, y0, x0);
-        load_halo1(g1, hal[buf], n, z0, y0, x0, D, H, W);
+        halo1_put(hal[buf], hr);
         __syncthreads();
+        if (br + 1 < b1) halo1_fetch(g1, hr, br + 1, nbd, nbh, nbw, D, H, W);
+        __builtin_amdgcn_sched_barrier(0);
         const int gz = z0 + wv;
         if (gz >= D) continue;
         const long base = ((((long)n * D + gz) * H + y0) * W + x0) * C + 4 * q;
@@ -393,11 +427,15 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
     const int b0 = blockIdx.x * bricks_per_block;
     const int b1 = b0 + bricks_per_block < nbricks ? b0 + bricks_per_block : nbricks;
     int buf = 0;
+    float hr[TH_PER_THREAD];
+    if (b0 < b1) halo1_fetch(a, hr, b0, nbd, nbh, nbw, D, H, W);
     for (int br = b0; br < b1; ++br, buf ^= 1) {
         int n, z0, y0, x0;
         brick_coords(br, nbd, nbh, nbw, n, z0, y0, x0);
-        load_halo1(a, hal[buf], n, z0, y0, x0, D, H, W);
+        halo1_put(hal[buf], hr);
         __syncthreads();
+        if (br + 1 < b1) halo1_fetch(a, hr, br + 1, nbd, nbh, nbw, D, H, W);
+        __builtin_amdgcn_sched_barrier(0);
         const int gz = z0 + wv;
         if (gz >= D) continue;
         const long base = ((((long)n * D + gz) * H + y0) * W + x0) * C + 4 * q;
@@ -1026,7 +1064,7 @@ __global__ __launch_bounds__(256) void thin_wg_k(const float* __restrict__ a,
 // one partial row per block is written, part[block][C][28], as above.
 // ---------------------------------------------------------------------------------
 template <bool BN>
-__global__ __launch_bounds__(256, BN ? 3 : 4) void thin_wg_mfma_k(const float* __restrict__ a,
+__global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict__ a,
                                                       const float* __restrict__ g,
                                                       float* __restrict__ part, int N, int D, int H, int W,
                                                       int C, int nbd, int nbh, int nbw,
@@ -1064,12 +1102,16 @@ __global__ __launch_bounds__(256, BN ? 3 : 4) void thin_wg_mfma_k(const float* _
     long b1 = b0 + bricks_per_block;
     if (b1 > nbricks) b1 = nbricks;
     int buf = 0;
+    float hr[TH_PER_THREAD];
+    if (b0 < b1) halo1_fetch(a, hr, (int)b0, nbd, nbh, nbw, D, H, W);
     for (long br = b0; br < b1; ++br, buf ^= 1) {
         int n, z0, y0, x0;
         brick_coords((int)br, nbd, nbh, nbw, n, z0, y0, x0);
         // two halo images: a wave still multiplying the previous brick reads the other one
-        load_halo1(a, hal[buf], n, z0, y0, x0, D, H, W);
+        halo1_put(hal[buf], hr);
         __syncthreads();
+        if (br + 1 < b1) halo1_fetch(a, hr, (int)br + 1, nbd, nbh, nbw, D, H, W);
+        __builtin_amdgcn_sched_barrier(0);
         const int gz = z0 + wv;
         if (gz >= D) continue;
         const float* gp = g + ((((long)n * D + gz) * H + y0) * W + x0) * C + 4 * q;
