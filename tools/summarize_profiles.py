@@ -36,7 +36,12 @@ def counters(d):
 def main():
     bench = json.loads(open(os.path.join(SRC, "bench_default.json")).read().strip().splitlines()[-1])
     vps = bench["value"]
+    for old in glob.glob(os.path.join(DST, f"{TAG}_bench_kernel_stats_*.csv")):
+        os.remove(old)
     shutil.copy(one("trace/vm/*_kernel_stats.csv"), os.path.join(DST, f"{TAG}_bench_kernel_stats_{vps:.1f}vps.csv"))
+    if glob.glob(os.path.join(SRC, "trace_serial/vm/*_kernel_stats.csv")):
+        shutil.copy(one("trace_serial/vm/*_kernel_stats.csv"),
+                    os.path.join(DST, f"{TAG}_bench_kernel_stats_serial.csv"))
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
             for r in csv.DictReader(open(one("trace/vm/*_kernel_trace.csv")))
             if DOM in r["Kernel_Name"] and r["Grid_Size_X"] == DOM_GRID]
