@@ -233,10 +233,9 @@ def main():
     B.conv3d_k3_fwd = timed(B.conv3d_k3_fwd)
     B.conv3d_k3_fwd_stats = timed(B.conv3d_k3_fwd_stats)
 
-    # ... and of two HBM-bound members of the step: the BatchNorm+LeakyReLU backward of a 64-channel
-    # full-resolution layer (reads dout and y, writes dy: 3 x 157 MB per volume, + keep mask where there is
-    # one) and the decoder's 64 -> 1 output convolution with its BatchNorm prologue (reads 157 MB, writes 2.5 MB per volume)
-    hbm_events = {"bn_act_bwd": [], "conv_64_to_1": []}
+    # ... and of three HBM-bound members of the step: the BatchNorm+LeakyReLU(+AvgPool) backward of a 64-channel
+    # full-resolution layer (reads y and the pooled dout, writes dy), the stem's fused BatchNorm backward and the decoder's 64 -> 1 output convolution with its BatchNorm prologue (reads 157 MB, writes 2.5 MB per volume)
+    hbm_events = {"bn_act_bwd": [], "stem_bn_bwd": [], "conv_64_to_1": []}
 
     def timed_hbm(orig, name, hit_fn, bytes_fn):
         def call(*a, **k):
@@ -253,8 +252,15 @@ def main():
     B.bn_act_bwd = timed_hbm(
         B.bn_act_bwd, "bn_act_bwd",
         # args after (dout, y): mean, var, gamma, beta, res, keep, p, slope, pool, eps, ...
-        lambda dout, y, *r: y.shape[1] == 64 and tuple(y.shape[2:]) == DIMS and r[8] == 1 and r[4] is None,
-        lambda dout, y, *r: 3 * y.numel() * 4 + (y.numel() if r[5] is not None else 0))
+        # the pooled BatchNorm behind the first wide encoder convolution: dout at 40x48x40, y and dy at 80x96x80
+        lambda dout, y, *r: y.shape[1] == 64 and tuple(y.shape[2:]) == DIMS and r[8] == 2 and r[4] is None,
+        lambda dout, y, *r: 2 * y.numel() * 4 + dout.numel() * 4)
+    # the encoder stem's BatchNorm backward (its convolution output is recomputed, not read): dout and the
+    # dropout mask read, the gradient of the convolution output written
+    B.conv1_bnact_bwd = timed_hbm(
+        B.conv1_bnact_bwd, "stem_bn_bwd",
+        lambda dout, *r: dout.shape[1] == 64 and tuple(dout.shape[2:]) == DIMS,
+        lambda dout, x, w, bias, mean, var, gamma, beta, keep, *r: 2 * dout.numel() * 4 + (dout.numel() if keep is not None else 0))
     # (the output convolution applies the BatchNorm + LeakyReLU of the block in front while it loads:
     # same bytes -- the raw 64-channel tensor read once, one channel written)
     B.bnact_conv_to1_fwd = timed_hbm(
