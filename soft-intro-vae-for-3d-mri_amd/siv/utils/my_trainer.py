@@ -169,9 +169,10 @@ class SoftIntroStep:
 class GraphedSoftIntroStep:
     """One ``SoftIntroStep`` iteration captured in a HIP graph and replayed.
 
-    An iteration is ~1300 kernel launches; issued one by one from Python they cost ~60 ms of host time,
-    which bounds small batches and the narrow FC-latent model.  Captured once (all forward passes, both
-    backward passes, both Adam updates) and replayed, the host cost is one graph launch.  What has to
+    An iteration is ~1250 kernel launches; issued one by one from Python they cost ~60 ms of host time.
+    Captured once (all forward passes, both backward passes, both Adam updates) and replayed, the host cost
+    is one graph launch (0.4 ms).  The device time does not change -- the iteration is GPU-bound even at
+    batch 1 -- so this is for callers that want the host thread back, not a speed-up.  What has to
     change from step to step lives in device memory: the inputs (copied into static buffers), the random
     stream (``DeviceRng`` epoch counter, advanced inside the graph), Adam's step count and learning rate
     (``FlatAdam.use_device_state``).  Requires the device generator, fixed batch shapes and a single
