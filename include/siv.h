@@ -126,20 +126,25 @@ int siv_conv3d_k3_wgrad(const float* x, const float* dy, float* dw, float* dbias
  * multiply-adds per element from the single-channel input, so it is never stored: the statistics
  * pass, the apply pass and both passes of the backward recompute it on the matrix pipe.
  * _fwd: x[N][D][H][W], w[Cout][27], out[N][D][H][W][Cout]; keep (uint8, layout of out) / p as in
- * siv_bn_act_fwd; train != 0: batch statistics are computed, written to mean / var[Cout] and folded
+ * siv_bn_act_fwd -- or keep == NULL with p > 0: the kernels draw the mask themselves, element i of out
+ * from component i % 4 of Philox(i / 4, mask_stream_id [+ *mask_epoch * 2^20], mask_seed), the bits
+ * siv_dropout_keep(_at) would have written, so no mask tensor exists (pass the same three values to
+ * _bwd); train != 0: batch statistics are computed, written to mean / var[Cout] and folded
  * into the running statistics (as siv_bn_stats); train == 0: mean / var are inputs.
  * _bwd: dout[N][D][H][W][Cout] -> dy = gradient of the (never stored) convolution output, which is
  * what siv_conv3d_k3_wgrad / _dgrad of the stem take; dgamma / dbeta written or (accumulate = 1) added.
  * Cout % 4 == 0, Cout <= 64 (siv_conv1_bnact_supported). */
 int siv_conv1_bnact_supported(int Cout);
 int siv_conv1_bnact_fwd(const float* x, const float* w, const float* bias, const float* gamma,
-                        const float* beta, const uint8_t* keep, float p, float slope, float eps, int train,
+                        const float* beta, const uint8_t* keep, uint64_t mask_seed, uint64_t mask_stream_id,
+                        const uint64_t* mask_epoch, float p, float slope, float eps, int train,
                         float* mean, float* var, float* running_mean, float* running_var,
                         int64_t* num_batches_tracked, float momentum, float* out,
                         int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, siv_stream_t stream);
 int siv_conv1_bnact_bwd(const float* dout, const float* x, const float* w, const float* bias,
                         const float* mean, const float* var, const float* gamma, const float* beta,
-                        const uint8_t* keep, float p, float slope, float eps, float* dy, float* dgamma,
+                        const uint8_t* keep, uint64_t mask_seed, uint64_t mask_stream_id,
+                        const uint64_t* mask_epoch, float p, float slope, float eps, float* dy, float* dgamma,
                         float* dbeta, int accumulate, int N, int D, int H, int W, int Cout,
                         void* ws, size_t ws_bytes, siv_stream_t stream);
 

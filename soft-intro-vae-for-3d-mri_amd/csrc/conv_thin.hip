@@ -388,13 +388,16 @@ template <int MODE>
 __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                                                     const float* __restrict__ w,
                                                     const float* __restrict__ bias, BnPrologue bn,
-                                                    const uint8_t* __restrict__ keep, float p,
+                                                    const uint8_t* __restrict__ keep, PhiloxMask rk, float p,
                                                     const float* __restrict__ dout,
                                                     const float* __restrict__ sums, float invM,
                                                     float* __restrict__ part, float* __restrict__ out,
                                                     int N, int D, int H, int W, int C, int nbd, int nbh,
                                                     int nbw, int bricks_per_block, int nbricks) {
     __shared__ float hal[2][TH_V];
+    // dropout: a mask tensor (keep), or the mask drawn here from the element index (rk.on), or none
+    const bool masked = MODE != SM_STATS && (keep != nullptr || rk.on);
+    const uint64_t rsid = (rk.on && rk.epoch) ? rk.sid + *rk.epoch * SIV_EPOCH_STRIDE : rk.sid;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = lane & 15, kk = lane >> 4;
     const bool qok = 4 * q < C;
@@ -472,6 +475,15 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
             for (int e = 0; e < 4; ++e) {
                 const float gg[4] = {gv[e].x, gv[e].y, gv[e].z, gv[e].w};
                 float o[4];
+                bool kp[4] = {true, true, true, true};
+                if (MODE != SM_STATS && keep) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) kp[j] = ((kv[e] >> (8 * j)) & 0xffu) != 0;
+                } else if (MODE != SM_STATS && rk.on) {
+                    const u4 r = philox4x32_10((uint64_t)(off[e] >> 2), rsid, rk.seed);
+                    kp[0] = philox_keeps(r.x, p); kp[1] = philox_keeps(r.y, p);
+                    kp[2] = philox_keeps(r.z, p); kp[3] = philox_keeps(r.w, p);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float v = acc[j][e];                  // bias-free convolution output
@@ -484,15 +496,14 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                     }
                     const float yv = v + bq[j];
                     const float z = fmaf(yv, ca[j], cb[j]);
-                    const bool kept = !keep || ((kv[e] >> (8 * j)) & 0xffu) != 0;
                     if (MODE == SM_APPLY) {
                         float r = z > 0.f ? z : z * bn.slope;
-                        if (keep) r = kept ? r * dscale : 0.f;
+                        if (masked) r = kp[j] ? r * dscale : 0.f;
                         o[j] = r;
                         continue;
                     }
                     float g = gg[j];
-                    if (keep) g = kept ? g * dscale : 0.f;
+                    if (masked) g = kp[j] ? g * dscale : 0.f;
                     const float dz = g * (z > 0.f ? 1.f : bn.slope);
                     const float xh = (yv - cm[j]) * ci[j];
                     if (MODE == SM_BSUM) {
@@ -1352,16 +1363,17 @@ static int stem_grid(const char* what, int N, int D, int H, int W, int C, size_t
 // Forward of Conv3d(1, C, 3) -> BatchNorm -> LeakyReLU -> Dropout.  train: batch statistics are computed
 // (mean, var written, running statistics updated); otherwise mean / var are used as given.
 int stem_bnact_fwd_launch(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
-                          const uint8_t* keep, float p, float slope, float eps, int train, float* mean, float* var,
-                          float* running_mean, float* running_var, int64_t* nbt, float momentum, float* out, int N,
-                          int D, int H, int W, int C, void* ws, size_t ws_bytes, hipStream_t s) {
+                          const uint8_t* keep, const PhiloxMask& rk, float p, float slope, float eps, int train,
+                          float* mean, float* var, float* running_mean, float* running_var, int64_t* nbt,
+                          float momentum, float* out, int N, int D, int H, int W, int C, void* ws, size_t ws_bytes,
+                          hipStream_t s) {
     StemGrid g;
     int rc = stem_grid("conv1_bnact_fwd", N, D, H, W, C, ws_bytes, g);
     if (rc) return rc;
     const BnPrologue bn{mean, var, gamma, beta, eps, slope};
     if (train) {
         float* part = (float*)ws;
-        stem_bn_k<SM_STATS><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, nullptr, 0.f, nullptr, nullptr, 0.f, part,
+        stem_bn_k<SM_STATS><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, nullptr, PhiloxMask{}, 0.f, nullptr, nullptr, 0.f, part,
                                                             nullptr, N, D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb,
                                                             (int)g.nbricks);
         SIV_CHECK_LAUNCH("conv1_bnact_fwd(statistics)");
@@ -1369,7 +1381,7 @@ int stem_bnact_fwd_launch(const float* x, const float* w, const float* bias, con
                                 nbt, momentum, s);
         if (rc) return rc;
     }
-    stem_bn_k<SM_APPLY><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, p, nullptr, nullptr, 0.f, nullptr, out, N,
+    stem_bn_k<SM_APPLY><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, nullptr, nullptr, 0.f, nullptr, out, N,
                                                         D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks);
     SIV_CHECK_LAUNCH("conv1_bnact_fwd(apply)");
     return SIV_OK;
@@ -1377,9 +1389,10 @@ int stem_bnact_fwd_launch(const float* x, const float* w, const float* bias, con
 
 // Backward of the same down to the convolution output: dy (gradient of the never-stored y), dgamma, dbeta.
 int stem_bnact_bwd_launch(const float* dout, const float* x, const float* w, const float* bias, const float* mean,
-                          const float* var, const float* gamma, const float* beta, const uint8_t* keep, float p,
-                          float slope, float eps, float* dy, float* dgamma, float* dbeta, int accumulate, int N,
-                          int D, int H, int W, int C, void* ws, size_t ws_bytes, hipStream_t s) {
+                          const float* var, const float* gamma, const float* beta, const uint8_t* keep,
+                          const PhiloxMask& rk, float p, float slope, float eps, float* dy, float* dgamma,
+                          float* dbeta, int accumulate, int N, int D, int H, int W, int C, void* ws, size_t ws_bytes,
+                          hipStream_t s) {
     StemGrid g;
     int rc = stem_grid("conv1_bnact_bwd", N, D, H, W, C, ws_bytes, g);
     if (rc) return rc;
@@ -1387,12 +1400,12 @@ int stem_bnact_bwd_launch(const float* dout, const float* x, const float* w, con
     float* part = (float*)ws;
     float* sums = (float*)((char*)ws + g.part_bytes);
     const float invM = 1.0f / (float)((long)N * D * H * W);
-    stem_bn_k<SM_BSUM><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, p, dout, nullptr, invM, part, nullptr, N, D,
+    stem_bn_k<SM_BSUM><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, dout, nullptr, invM, part, nullptr, N, D,
                                                        H, W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks);
     SIV_CHECK_LAUNCH("conv1_bnact_bwd(sums)");
     rc = bn_bwd_finalize_launch(part, (int)g.nblk, C, sums, dgamma, dbeta, accumulate, s);
     if (rc) return rc;
-    stem_bn_k<SM_BAPP><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, p, dout, sums, invM, nullptr, dy, N, D, H,
+    stem_bn_k<SM_BAPP><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, dout, sums, invM, nullptr, dy, N, D, H,
                                                        W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks);
     SIV_CHECK_LAUNCH("conv1_bnact_bwd(apply)");
     return SIV_OK;

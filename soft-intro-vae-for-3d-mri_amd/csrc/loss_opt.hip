@@ -231,33 +231,13 @@ __global__ __launch_bounds__(256) void axpby_k(float a, const float* __restrict_
         y[i] = (b == 0.f) ? a * x[i] : fmaf(a, x[i], b * y[i]);
 }
 
-// ---- Philox-4x32-10 ---------------------------------------------------------------
-struct u4 { uint32_t x, y, z, w; };
-__device__ __forceinline__ u4 philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
-    uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
-    uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
-    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return u4{c0, c1, c2, c3};
-}
+// ---- Philox-4x32-10 (siv_common.h) --------------------------------------------------
 __device__ __forceinline__ float u01(uint32_t r) {  // (0,1]
     return ((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }
 
 // epoch (optional, device memory): added to the stream id in steps of 2^20, so that a launch captured in a
 // HIP graph draws fresh numbers on every replay once the counter has been advanced
-#define SIV_EPOCH_STRIDE (1ull << 20)
 __global__ __launch_bounds__(256) void randn_k(float* __restrict__ out, long n, uint64_t seed,
                                                uint64_t sid, const unsigned long long* __restrict__ epoch) {
     if (epoch) sid += *epoch * SIV_EPOCH_STRIDE;
@@ -285,7 +265,7 @@ __global__ __launch_bounds__(256) void dropout_keep_k(uint8_t* __restrict__ keep
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (q * 4 + j < n)
-                keep[q * 4 + j] = ((float)(rr[j] >> 8) * (1.0f / 16777216.0f)) >= p ? 1 : 0;
+                keep[q * 4 + j] = philox_keeps(rr[j], p) ? 1 : 0;
     }
 }
 

@@ -148,13 +148,15 @@ int k3_thin_bn_dgrad_launch(const float* g1, const float* w, const float* x, con
                             float* dgamma, float* dbeta, int accumulate, int N, int D, int H, int W, int Cin,
                             void* ws, size_t ws_bytes, hipStream_t s);
 int stem_bnact_fwd_launch(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
-                          const uint8_t* keep, float p, float slope, float eps, int train, float* mean, float* var,
-                          float* running_mean, float* running_var, int64_t* nbt, float momentum, float* out, int N,
-                          int D, int H, int W, int C, void* ws, size_t ws_bytes, hipStream_t s);
+                          const uint8_t* keep, const PhiloxMask& rk, float p, float slope, float eps, int train,
+                          float* mean, float* var, float* running_mean, float* running_var, int64_t* nbt,
+                          float momentum, float* out, int N, int D, int H, int W, int C, void* ws, size_t ws_bytes,
+                          hipStream_t s);
 int stem_bnact_bwd_launch(const float* dout, const float* x, const float* w, const float* bias, const float* mean,
-                          const float* var, const float* gamma, const float* beta, const uint8_t* keep, float p,
-                          float slope, float eps, float* dy, float* dgamma, float* dbeta, int accumulate, int N,
-                          int D, int H, int W, int C, void* ws, size_t ws_bytes, hipStream_t s);
+                          const float* var, const float* gamma, const float* beta, const uint8_t* keep,
+                          const PhiloxMask& rk, float p, float slope, float eps, float* dy, float* dgamma,
+                          float* dbeta, int accumulate, int N, int D, int H, int W, int C, void* ws, size_t ws_bytes,
+                          hipStream_t s);
 bool k3_thin_bn_fwd_supported(int N, int D, int H, int W, int Cin);
 int k3_thin_bn_fwd_launch(const float* x, const BnPrologue& bn, const float* w, const float* bias, float* out,
                           int N, int D, int H, int W, int Cin, hipStream_t s);
@@ -228,7 +230,7 @@ using namespace siv;
 
 extern "C" const char* siv_last_error(void) { return g_err; }
 extern "C" const char* siv_last_conv_kernel(void) { return g_conv_kernel; }
-extern "C" int siv_version(void) { return 104; }
+extern "C" int siv_version(void) { return 105; }
 extern "C" size_t siv_workspace_bytes(void) { return (size_t)512 << 20; }
 extern "C" int siv_pack_cache_configure(void* mem, size_t bytes) {
     SIV_CHECK_ARG(((uintptr_t)mem & 255) == 0, "pack_cache_configure: memory must be 256-byte aligned");
@@ -365,8 +367,9 @@ extern "C" int siv_conv1_bnact_supported(int Cout) {
     return conv_path() != 1 && Cout % 4 == 0 && Cout >= 4 && Cout <= 64 ? 1 : 0;
 }
 extern "C" int siv_conv1_bnact_fwd(const float* x, const float* w, const float* bias, const float* gamma,
-                                   const float* beta, const uint8_t* keep, float p, float slope, float eps,
-                                   int train, float* mean, float* var, float* running_mean,
+                                   const float* beta, const uint8_t* keep, uint64_t mask_seed,
+                                   uint64_t mask_stream_id, const uint64_t* mask_epoch, float p, float slope,
+                                   float eps, int train, float* mean, float* var, float* running_mean,
                                    float* running_var, int64_t* num_batches_tracked, float momentum,
                                    float* out, int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes,
                                    siv_stream_t stream) {
@@ -379,13 +382,16 @@ extern "C" int siv_conv1_bnact_fwd(const float* x, const float* w, const float* 
     SIV_CHECK_ARG(aligned16(out) && aligned16(ws) && ((uintptr_t)keep & 3) == 0,
                   "conv1_bnact_fwd: out and the workspace must be 16-byte aligned, keep 4-byte aligned");
     SIV_PICK("thin");
-    return stem_bnact_fwd_launch(x, w, bias, gamma, beta, keep, p, slope, eps, train, mean, var, running_mean,
+    // no mask tensor and p > 0: the mask is drawn inside the kernels from (seed, stream id [, epoch])
+    const PhiloxMask rk{mask_seed, mask_stream_id, (const unsigned long long*)mask_epoch, keep == nullptr && p > 0.f};
+    return stem_bnact_fwd_launch(x, w, bias, gamma, beta, keep, rk, p, slope, eps, train, mean, var, running_mean,
                                  running_var, num_batches_tracked, momentum, out, N, D, H, W, Cout, ws, ws_bytes,
                                  (hipStream_t)stream);
 }
 extern "C" int siv_conv1_bnact_bwd(const float* dout, const float* x, const float* w, const float* bias,
                                    const float* mean, const float* var, const float* gamma, const float* beta,
-                                   const uint8_t* keep, float p, float slope, float eps, float* dy,
+                                   const uint8_t* keep, uint64_t mask_seed, uint64_t mask_stream_id,
+                                   const uint64_t* mask_epoch, float p, float slope, float eps, float* dy,
                                    float* dgamma, float* dbeta, int accumulate, int N, int D, int H, int W,
                                    int Cout, void* ws, size_t ws_bytes, siv_stream_t stream) {
     SIV_CHECK_ARG(dout && x && w && mean && var && gamma && beta && dy, "conv1_bnact_bwd: null pointer");
@@ -396,7 +402,8 @@ extern "C" int siv_conv1_bnact_bwd(const float* dout, const float* x, const floa
     SIV_CHECK_ARG(aligned16(dout) && aligned16(dy) && aligned16(ws) && ((uintptr_t)keep & 3) == 0,
                   "conv1_bnact_bwd: dout, dy and the workspace must be 16-byte aligned, keep 4-byte aligned");
     SIV_PICK("thin");
-    return stem_bnact_bwd_launch(dout, x, w, bias, mean, var, gamma, beta, keep, p, slope, eps, dy, dgamma, dbeta,
+    const PhiloxMask rk{mask_seed, mask_stream_id, (const unsigned long long*)mask_epoch, keep == nullptr && p > 0.f};
+    return stem_bnact_bwd_launch(dout, x, w, bias, mean, var, gamma, beta, keep, rk, p, slope, eps, dy, dgamma, dbeta,
                                  accumulate, N, D, H, W, Cout, ws, ws_bytes, (hipStream_t)stream);
 }
 

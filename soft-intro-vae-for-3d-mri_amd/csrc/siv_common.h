@@ -81,6 +81,41 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh /* >= 4 floats
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// ---- Philox-4x32-10: counter = element quad, high counter word = stream id, key = seed -----------
+struct u4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ u4 philox4x32_10(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
+    uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
+    uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return u4{c0, c1, c2, c3};
+}
+// the Bernoulli(1 - p) draw behind one 32-bit output: dropout keeps the element when this is true
+__device__ __forceinline__ bool philox_keeps(uint32_t r, float p) {
+    return ((float)(r >> 8) * (1.0f / 16777216.0f)) >= p;
+}
+// epoch (optional, device memory): added to the stream id in steps of 2^20, so that a launch captured in a
+// HIP graph draws fresh numbers on every replay once the counter has been advanced
+#define SIV_EPOCH_STRIDE (1ull << 20)
+// Dropout mask drawn where it is used instead of read from a tensor: element i of the masked tensor is
+// component i % 4 of philox(i / 4, stream id, seed) -- the very bits siv_dropout_keep writes.
+struct PhiloxMask {
+    uint64_t seed, sid;
+    const unsigned long long* epoch;
+    int on;
+};
+
 __device__ __forceinline__ float leaky(float z, float slope) { return z > 0.f ? z : z * slope; }
 __device__ __forceinline__ float leaky_grad(float z, float slope) { return z > 0.f ? 1.f : slope; }
 

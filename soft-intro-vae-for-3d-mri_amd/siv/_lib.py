@@ -27,10 +27,10 @@ SIGNATURES = {
     "siv_conv_transpose3d_k3_dgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_conv_transpose3d_k3_wgrad": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_conv1_bnact_supported": [_i],
-    "siv_conv1_bnact_fwd": [_f, _f, _f, _f, _f, _f, _fl, _fl, _fl, _i, _f, _f, _f, _f, _f, _fl, _f, _i, _i, _i, _i, _i,
-                            _f, _sz, _f],
-    "siv_conv1_bnact_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _fl, _fl, _fl, _f, _f, _f, _i, _i, _i, _i, _i, _i,
-                            _f, _sz, _f],
+    "siv_conv1_bnact_fwd": [_f, _f, _f, _f, _f, _f, _u64, _u64, _f, _fl, _fl, _fl, _i, _f, _f, _f, _f, _f, _fl, _f,
+                            _i, _i, _i, _i, _i, _f, _sz, _f],
+    "siv_conv1_bnact_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _u64, _u64, _f, _fl, _fl, _fl, _f, _f, _f, _i,
+                            _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_bnact_conv3d_k3_to1_supported": [_i, _i, _i, _i, _i],
     "siv_bnact_conv3d_k3_to1_fwd": [_f, _f, _f, _f, _f, _fl, _fl, _f, _f, _f, _i, _i, _i, _i, _i, _f],
     "siv_bnact_conv3d_k3_to1_dgrad": [_f, _f, _f, _f, _f, _f, _f, _fl, _fl, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],

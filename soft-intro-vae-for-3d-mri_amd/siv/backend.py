@@ -216,12 +216,24 @@ class HipBackend:
         return bool(x.is_cuda and x.dim() == 5 and x.shape[1] == 1 and
                     self.lib.siv_conv1_bnact_supported(int(w.shape[0])))
 
+    @staticmethod
+    def _mask_args(keep):
+        """(mask tensor or None, (seed, stream id, epoch counter)) from a uint8 tensor, a key object with
+        ``seed`` / ``stream_id`` / ``epoch`` (mask drawn by the kernels), or None."""
+        if keep is None:
+            return None, (0, 0, None)
+        if torch.is_tensor(keep):
+            return cl(keep), (0, 0, None)
+        m = 2 ** 64 - 1
+        return None, (keep.seed & m, keep.stream_id & m, keep.epoch)
+
     def conv1_bnact_fwd(self, x, w, bias, gamma, beta, keep, p, slope, eps, train: bool, running_mean,
                         running_var, nbt, momentum: float):
         """Returns (out, mean, var); in evaluation mode mean / var are the running statistics."""
-        self._check_dev(x, w, bias, gamma, beta, keep, running_mean, running_var, nbt)
+        masked = keep is not None       # the C entry point reads "no mask tensor, p > 0" as "draw the mask"
+        keep, mk = self._mask_args(keep)
+        self._check_dev(x, w, bias, gamma, beta, keep, mk[2], running_mean, running_var, nbt)
         x, w = x.contiguous(), cl(w)
-        keep = cl(keep) if keep is not None else None
         N, _, D, H, W = x.shape
         C = w.shape[0]
         out = empty_cl((N, C, D, H, W), x)
@@ -232,8 +244,9 @@ class HipBackend:
         else:
             mean, var, rm, rv, nb = running_mean, running_var, None, None, None
         ws, wsb = self._workspace(x)
-        _lib.check(self.lib.siv_conv1_bnact_fwd(_p(x), _p(w), _p(bias), _p(gamma), _p(beta), _p(keep), float(p),
-                                                float(slope), float(eps), int(train), _p(mean), _p(var), _p(rm),
+        _lib.check(self.lib.siv_conv1_bnact_fwd(_p(x), _p(w), _p(bias), _p(gamma), _p(beta), _p(keep), mk[0], mk[1],
+                                                _p(mk[2]), float(p) if masked else 0.0, float(slope), float(eps),
+                                                int(train), _p(mean), _p(var), _p(rm),
                                                 _p(rv), _p(nb), float(momentum), _p(out), N, D, H, W, C, ws, wsb,
                                                 self._stream(x)), "siv_conv1_bnact_fwd")
         return out, mean, var
@@ -241,9 +254,10 @@ class HipBackend:
     def conv1_bnact_bwd(self, dout, x, w, bias, mean, var, gamma, beta, keep, p, slope, eps,
                         want_affine: bool, dgamma_out=None, dbeta_out=None):
         """Gradient of the convolution output (and of gamma / beta: returned, or ADDED into the buffers)."""
-        self._check_dev(dout, x, w, bias, mean, var, gamma, beta, keep, dgamma_out, dbeta_out)
+        masked = keep is not None
+        keep, mk = self._mask_args(keep)
+        self._check_dev(dout, x, w, bias, mean, var, gamma, beta, keep, mk[2], dgamma_out, dbeta_out)
         dout, x, w = cl(dout), x.contiguous(), cl(w)
-        keep = cl(keep) if keep is not None else None
         N, C, D, H, W = dout.shape
         dy = like(dout)
         acc = 0
@@ -255,7 +269,8 @@ class HipBackend:
             dbeta = torch.empty(C, device=x.device, dtype=torch.float32) if want_affine else None
         ws, wsb = self._workspace(dout)
         _lib.check(self.lib.siv_conv1_bnact_bwd(_p(dout), _p(x), _p(w), _p(bias), _p(mean), _p(var), _p(gamma),
-                                                _p(beta), _p(keep), float(p), float(slope), float(eps), _p(dy),
+                                                _p(beta), _p(keep), mk[0], mk[1], _p(mk[2]),
+                                                float(p) if masked else 0.0, float(slope), float(eps), _p(dy),
                                                 _p(dgamma), _p(dbeta), acc, N, D, H, W, C, ws, wsb,
                                                 self._stream(dout)), "siv_conv1_bnact_bwd")
         return dy, dgamma, dbeta

@@ -38,10 +38,13 @@ def _act_module(v: Variant) -> nn.Module:
     return nn.LeakyReLU(v.slope, inplace=True) if v.slope != 0.0 else nn.ReLU(inplace=True)
 
 
-def _keep(shape, p: float, training: bool, device):
+def _keep(shape, p: float, training: bool, device, stored: bool = True):
+    """The dropout mask of one call site; ``stored=False`` asks for the key of the mask instead of the
+    tensor (consumers that draw it themselves)."""
     if not training or p == 0.0:
         return None
-    return rng.get_rng().keep_mask(shape, p, device)
+    r = rng.get_rng()
+    return r.keep_mask(shape, p, device) if stored else r.keep_mask_key(shape, p, device)
 
 
 def _shortcut(in_ch: int, out_ch: int):
@@ -154,8 +157,10 @@ class ResNetEncoder(nn.Module):
     def features(self, x):
         v = self.variant
         conv, bn = self.blocks[0][0], self.blocks[0][1]
-        keep = _keep((x.shape[0], conv.out_channels) + tuple(x.shape[2:]), v.p_enc_stem, self.training, x.device)
-        if ops.conv1_bn_act_supported(x, conv):      # the stem's convolution output is never stored
+        fused = ops.conv1_bn_act_supported(x, conv)  # the stem's convolution output and mask are never stored
+        keep = _keep((x.shape[0], conv.out_channels) + tuple(x.shape[2:]), v.p_enc_stem, self.training, x.device,
+                     stored=not fused)
+        if fused:
             h = ops.conv1_bn_act(x, conv, bn, v.slope, keep=keep, p=v.p_enc_stem, train=self.training)
         else:
             h = ops.conv_bn_act(x, conv, bn, v.slope, keep=keep, p=v.p_enc_stem, train=self.training)

@@ -302,7 +302,8 @@ class _Conv1BnAct(Function):
         out, mean, var = B.conv1_bnact_fwd(x, w, bias, gamma, beta, keep, p, slope, bn.eps, train,
                                            bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                            BN_MOMENTUM if bn.momentum is None else bn.momentum)
-        ctx.save_for_backward(x, w, bias, mean, var, gamma, beta, keep)
+        ctx.mask_key = None if keep is None or torch.is_tensor(keep) else keep   # a mask drawn in-kernel
+        ctx.save_for_backward(x, w, bias, mean, var, gamma, beta, keep if ctx.mask_key is None else None)
         ctx.cfg = (p, slope, bn.eps, train)
         ctx.bufs = (_grad_buf(w), _grad_buf(bias), _grad_buf(gamma), _grad_buf(beta))
         return out
@@ -310,6 +311,8 @@ class _Conv1BnAct(Function):
     @staticmethod
     def backward(ctx, dout):
         x, w, bias, mean, var, gamma, beta, keep = ctx.saved_tensors
+        if ctx.mask_key is not None:
+            keep = ctx.mask_key
         p, slope, eps, train = ctx.cfg
         w_buf, cb_buf, g_buf, b_buf = ctx.bufs
         if not train:
@@ -347,7 +350,8 @@ def conv1_bn_act_supported(x, conv) -> bool:
 
 def conv1_bn_act(x, conv, bn, slope: float, keep=None, p: float = 0.0, train: bool = True):
     """``dropout(LeakyReLU(bn(conv(x))))`` for a single-channel input as one operator (see
-    ``conv1_bn_act_supported``); the fallback is ``conv_bn_act``."""
+    ``conv1_bn_act_supported``); the fallback is ``conv_bn_act``.  ``keep`` is a uint8 mask tensor or a
+    ``rng.PhiloxKeep`` key, for which the kernels draw the mask themselves."""
     return _Conv1BnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, keep, bn, p, slope, train)
 
 

@@ -18,6 +18,21 @@ import torch
 from .backend import get_backend
 
 
+class PhiloxKeep:
+    """A dropout keep mask that is never stored: the operator that consumes it draws element ``i`` (memory
+    order of the masked tensor) from Philox(i // 4, stream_id [+ epoch * 2^20], seed), the bits
+    ``HipBackend.dropout_keep`` writes for the same key.  Forward and backward of the operator both read the
+    epoch counter when they run, so it must not advance between them."""
+
+    __slots__ = ("seed", "stream_id", "epoch")
+
+    def __init__(self, seed: int, stream_id: int, epoch=None):
+        self.seed, self.stream_id, self.epoch = int(seed), int(stream_id), epoch
+
+    def materialise(self, shape, p: float, device) -> torch.Tensor:
+        return get_backend().dropout_keep(shape, device, p, self.seed, self.stream_id, self.epoch)
+
+
 class DeviceRng:
     """Philox-4x32-10 on the device; call ``i`` of rank ``r`` uses stream id (r << 40) | i."""
 
@@ -49,6 +64,11 @@ class DeviceRng:
     def keep_mask(self, shape, p: float, device) -> torch.Tensor:
         return get_backend().dropout_keep(shape, device, p, self.seed, self._sid(), self.epoch)
 
+    def keep_mask_key(self, shape, p: float, device) -> PhiloxKeep:
+        """The key of the mask ``keep_mask`` would return (same stream id consumed), for operators that
+        draw the mask themselves."""
+        return PhiloxKeep(self.seed, self._sid(), self.epoch)
+
     def eps(self, shape, device) -> torch.Tensor:
         return get_backend().randn(shape, device, self.seed, self._sid(), self.epoch)
 
@@ -63,6 +83,8 @@ class ReplayRng:
     def keep_mask(self, shape, p: float, device) -> torch.Tensor:
         m = self.source.mask(tuple(shape), p)
         return m.to(torch.uint8).to(device).contiguous(memory_format=torch.channels_last_3d)
+
+    keep_mask_key = keep_mask       # replayed masks are explicit tensors
 
     def eps(self, shape, device) -> torch.Tensor:
         return self.source.eps(tuple(shape)).to(device)

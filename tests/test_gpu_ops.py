@@ -558,6 +558,55 @@ def test_conv1_bnact_matches_separate_ops(B, C, dims, n, p):
     check(outs[0][2], wd.grad.float(), "dw against float64")
 
 
+@pytest.mark.parametrize("C,dims,n,p,epoch", [(64, (9, 10, 11), 2, 0.25, None), (64, (16, 12, 8), 1, 0.25, 3),
+                                              (12, (6, 7, 5), 2, 0.5, 0), (16, (5, 9, 6), 3, 0.1, 70000)])
+def test_conv1_bnact_draws_the_mask_it_would_have_read(B, C, dims, n, p, epoch):
+    """Dropout of the fused stem with the mask drawn inside the kernels from (seed, stream id, epoch
+    counter) instead of read from a tensor: forward output and all backward results are bit-identical to
+    the same calls fed the mask ``dropout_keep`` materialises for that key, with and without the device
+    epoch counter, through the raw operator and through autograd."""
+    import siv.ops as ops
+    from siv.rng import PhiloxKeep
+    gen = torch.Generator().manual_seed(C * 3 + n)
+    D, H, W = dims
+    slope, eps = 0.2, 1e-5
+    x = dev(torch.rand(n, 1, D, H, W, generator=gen))
+    w, b = dev(rnd(gen, C, 1, 3, 3, 3, scale=0.4)), dev(rnd(gen, C))
+    gamma, beta = dev(1 + 0.3 * rnd(gen, C)), dev(0.2 * rnd(gen, C))
+    dout = dev(rnd(gen, n, C, D, H, W))
+    ep = None if epoch is None else torch.tensor([epoch], dtype=torch.int64, device="cuda")
+    key = PhiloxKeep(seed=0x9E3779B97F4A7C15, stream_id=(2 << 40) | 17, epoch=ep)
+    mask = key.materialise((n, C, D, H, W), p, "cuda")
+    frac = float(mask.float().mean())
+    assert abs(frac - (1 - p)) < 0.03, frac
+    res = []
+    for keep in (mask, key):
+        rm, rv, nbt = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.tensor(0, device="cuda")
+        out, mean, var = B.conv1_bnact_fwd(x, w, b, gamma, beta, keep, p, slope, eps, True, rm, rv, nbt, 0.1)
+        dy, dg, db = B.conv1_bnact_bwd(dout, x, w, b, mean, var, gamma, beta, keep, p, slope, eps, True)
+        res.append((out, dy, dg, db))
+    for a_, b_, what in zip(res[0], res[1], ("out", "dy", "dgamma", "dbeta")):
+        assert torch.equal(a_, b_), what
+    assert float((res[0][0] == 0).float().mean()) > 0.5 * p        # the mask did drop elements
+    if epoch is not None:           # another epoch, another mask
+        ep.add_(1)
+        assert not torch.equal(key.materialise((n, C, D, H, W), p, "cuda"), mask)
+        ep.sub_(1)
+    outs = []
+    for keep in (mask, key):
+        bn = torch.nn.BatchNorm3d(C).to("cuda").train()
+        conv = torch.nn.Conv3d(1, C, 3, 1, 1).to("cuda")
+        with torch.no_grad():
+            bn.weight.copy_(gamma); bn.bias.copy_(beta); conv.weight.copy_(w); conv.bias.copy_(b)
+        xg = x.clone().requires_grad_(True)
+        o = ops.conv1_bn_act(xg, conv, bn, slope, keep=keep, p=p, train=True)
+        o.backward(dout)
+        torch.cuda.synchronize()
+        outs.append((o.detach(), xg.grad, conv.weight.grad, bn.weight.grad, bn.bias.grad))
+    for a_, b_, what in zip(outs[0], outs[1], ("out", "dx", "dw", "dgamma", "dbeta")):
+        assert torch.equal(a_, b_), "operator: " + what
+
+
 @pytest.mark.parametrize("dims,n", [((16, 24, 32), 2), ((19, 44, 36), 1), ((16, 12, 16), 3)])
 def test_bnact_conv_to1_matches_separate_ops(B, dims, n):
     """BatchNorm + LeakyReLU folded into the 64 -> 1 output convolution (models/models.py:76-78,137):
