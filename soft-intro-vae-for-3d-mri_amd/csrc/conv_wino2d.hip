@@ -13,8 +13,8 @@
 //   a block = 8 waves: wave (ph, wn) owns the four positions (ph, 0..3) of both row tiles for output
 //             channel half wn (8 accumulators = 128 registers)
 //
-// The transformed input V[pos][plane][tile][ci] of one 8-channel chunk takes 72 KB of LDS, so one block
-// runs per CU and nothing else would cover its barriers: V is double buffered.  While the waves multiply
+// The transformed input V[pos][plane][tile][ci] of one 8-channel chunk takes 48 KB of LDS and the epilogue
+// 144 KB, so one block runs per CU and nothing else would cover its barriers: V is double buffered.  While the waves multiply
 // chunk c out of one buffer, six of the eight waves transform the 4x4 patches of chunk c+1 (fetched into
 // registers at the end of chunk c-1; overlapping patches: L1/L2 hits) and fill the other buffer; one barrier
 // per chunk.  The output transform along W is done on the accumulators, the one along H needs the four
@@ -48,11 +48,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct W2Cfg {
     static constexpr int BD = 4, BH = 8, BW = 8;
-    static constexpr int CK = 8, CKP = 12;
+    static constexpr int CK = 8;
     static constexpr int TPP = 16;                         // 4x4 tiles per plane
     static constexpr int HD = BD + 2;                      // planes incl. halo
-    static constexpr int PLANE = HD * TPP * CKP;           // floats of one position: 1152
-    static constexpr int V_FLOATS = 16 * PLANE;            // 18432 floats = 72 KB
+    static constexpr int PLANE = HD * TPP * CK;            // floats of one position: 768
+    static constexpr int V_FLOATS = 16 * PLANE;            // 12288 floats = 48 KB
     static constexpr int NTHR = 512, NT = 64;
     static constexpr int TAPS = 48, SLICE = NT * 8;        // (kd, ph, pw) slices of [64 co][8 ci]
 #ifndef SIV_W2PD
@@ -60,9 +60,9 @@ struct W2Cfg {
 #endif
     static constexpr int PD = SIV_W2PD;                    // weight fragments fetched PD taps ahead (divides 12)
     static constexpr int EPI_STRIDE = 36, EPI_TILE = 32 * EPI_STRIDE;
-    static constexpr int LDS_FLOATS = 2 * V_FLOATS;
+    static constexpr int LDS_FLOATS = 32 * EPI_TILE;       // the epilogue holds all 32 tiles at once (144 KB)
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
-    static_assert(32 * EPI_TILE <= LDS_FLOATS, "all 32 epilogue tiles fit at once");
+    static_assert(2 * V_FLOATS <= LDS_FLOATS, "both V buffers fit");
 };
 
 __device__ __forceinline__ float4 w2sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -105,8 +105,12 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][a][r] = 0.f;
 
-    // A row m = a*32 + li is tile (dz = m >> 4, th, tw): its V offset is linear in li
-    const int aoff0 = ph * 4 * C::PLANE + li * C::CKP + 4 * lh;       // + a*384 + kd*192 + pw*PLANE
+    // A row m = a*32 + li is tile (dz = m >> 4, th, tw) and reads V row (dz + kd)*16 + tile = m + 16*kd.
+    // A V row holds the 8 channels of a chunk without padding; the two 16-byte halves of the rows of an odd
+    // halo plane are swapped, which spreads the 16 lanes that share an LDS cycle over all 64 banks (lanes li
+    // and li + 16 meet in one cycle and are 128 floats apart) and makes the staging writes conflict-free.
+    const int aoff0 = ph * 4 * C::PLANE + li * C::CK + 4 * (lh ^ ((li >> 4) & 1));   // kd even; + a*256 + kd*128 + pw*PLANE
+    const int aoff1 = aoff0 ^ 4;                                                        // kd odd
     // this lane's B fragment inside a packed [64 co][8 ci] slice; slices of this wave: kd*16 + ph*4 + pw
     const float* wlane = wp + ((long)blockIdx.y * nchunk * C::TAPS + ph * 4) * C::SLICE + (wn * 32 + li) * 8 + 4 * lh;
     constexpr int PD = C::PD;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             patch[rr * 4 + 0] = t0; patch[rr * 4 + 1] = t1; patch[rr * 4 + 2] = t2; patch[rr * 4 + 3] = t3;
         } else {
             const int pw = piece - 4;
-            float* dst = buf + s_r * C::CKP + 2 * s_q + pw * C::PLANE;
+            float* dst = buf + s_r * C::CK + ((2 * s_q) ^ (4 * (s_hz & 1))) + pw * C::PLANE;
             *reinterpret_cast<float2*>(dst + 0 * 4 * C::PLANE) = w2sub(patch[0 * 4 + pw], patch[2 * 4 + pw]);
             *reinterpret_cast<float2*>(dst + 1 * 4 * C::PLANE) = w2add(patch[1 * 4 + pw], patch[2 * 4 + pw]);
             *reinterpret_cast<float2*>(dst + 2 * 4 * C::PLANE) = w2sub(patch[2 * 4 + pw], patch[1 * 4 + pw]);
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
         const float* wc = wlane + (long)cc * C::TAPS * C::SLICE;
         float4 anext[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) anext[a] = *reinterpret_cast<const float4*>(cur + aoff0 + a * 384);
+        for (int a = 0; a < 2; ++a) anext[a] = *reinterpret_cast<const float4*>(cur + aoff0 + a * 256);
 #pragma unroll
         for (int t = 0; t < 12; ++t) {                     // t = kd*4 + pw
             const int pw = t & 3;
@@ -216,11 +220,12 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             }
             if (t + 1 < 12) {
                 const int t1 = t + 1;
-                const int tapoff = (t1 & 3) * C::PLANE + (t1 >> 2) * 192;
+                const int tapoff = (t1 & 3) * C::PLANE + (t1 >> 2) * 128;
+                const int abase = (t1 >> 2) == 1 ? aoff1 : aoff0;
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
                     if (SIV_W2EXP & 8) asm volatile("" : "+v"(anext[a].x), "+v"(anext[a].y), "+v"(anext[a].z), "+v"(anext[a].w));
-                    else anext[a] = *reinterpret_cast<const float4*>(cur + aoff0 + a * 384 + tapoff);
+                    else anext[a] = *reinterpret_cast<const float4*>(cur + abase + a * 256 + tapoff);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
