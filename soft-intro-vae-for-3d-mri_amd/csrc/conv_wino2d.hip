@@ -45,6 +45,16 @@ __device__ unsigned long long w2_stamps[2048 * 8 * 32];
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float w2f4 __attribute__((ext_vector_type(4)));
+
+// 16 bytes through a buffer descriptor: byte offset = per-lane voff + wave-uniform soff (+ an immediate the
+// compiler folds); no 64-bit address arithmetic on the vector ALU, and a lane whose voff lies beyond the
+// descriptor's size reads zeros without touching memory.
+__device__ __forceinline__ float4 w2_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    const w2f4 f = __builtin_bit_cast(w2f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+constexpr unsigned W2_OUTSIDE = 0x80000000u;      // beyond any sample (the launcher keeps samples below 2 GiB)
 
 struct W2Cfg {
     static constexpr int BD = 4, BH = 8, BW = 8;
@@ -60,9 +70,11 @@ struct W2Cfg {
 #endif
     static constexpr int PD = SIV_W2PD;                    // weight fragments fetched PD taps ahead (divides 12)
     static constexpr int EPI_STRIDE = 36, EPI_TILE = 32 * EPI_STRIDE;
+    static constexpr int RAW_ITEMS = 3 * NTHR;             // 16-byte items of a raw halo image (1536 >= 2 * 600)
+    static constexpr int RAW_FLOATS = RAW_ITEMS * 4;       // 6144 floats = 24 KB
     static constexpr int LDS_FLOATS = 32 * EPI_TILE;       // the epilogue holds all 32 tiles at once (144 KB)
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
-    static_assert(2 * V_FLOATS <= LDS_FLOATS, "both V buffers fit");
+    static_assert(2 * V_FLOATS + 2 * RAW_FLOATS <= LDS_FLOATS, "both V buffers and both raw images fit");
 };
 
 __device__ __forceinline__ float4 w2sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -70,14 +82,27 @@ __device__ __forceinline__ float4 w2add(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float2 w2sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 w2add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 
+#ifndef SIV_W2ROUNDS
+#define SIV_W2ROUNDS 1
+#endif
+
+// TPR = tiles per row of a brick plane: 4 (8 x 8 voxels, 16 tiles) or 5 (6 x 10 voxels, 15 tiles: slot 15
+// empty).  ROUNDS = 1: a staging item is (tile-row, channel pair), 384 items = waves 0..5; ROUNDS = 2: an item
+// is (tile-row, channel quad) handled as two pairs in turn, 192 items = waves 0..2.
+template <int TPR, int ROUNDS>
 __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict__ x,
                                                         const float* __restrict__ wp,
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ y, int N, int D, int H, int W,
                                                         int Cin, int Cout, int nbd, int nbh, int nbw,
-                                                        float* __restrict__ stat_part, int tpr) {
+                                                        float* __restrict__ stat_part) {
     using C = W2Cfg;
+    constexpr int tpr = TPR, trows = 16 / TPR;
+    constexpr int BHP = 2 * trows + 2, BWP = 2 * TPR + 2;      // halo plane: 10 x 10 or 8 x 12 voxels
+    constexpr int NV = C::HD * BHP * BWP;                      // 600 or 576 halo voxels
+    static_assert(2 * NV <= C::RAW_ITEMS, "three 16-byte items per thread cover the halo");
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const rimg = lds + 2 * C::V_FLOATS;                 // two raw halo images
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -91,11 +116,111 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     const int by = b % nbh; b /= nbh;
     const int bz = b % nbd;
     const int n = b / nbd;
-    // tiles per row of a brick plane: 4 (8 x 8 voxels, 16 tiles) or 5 (6 x 10 voxels, 15 tiles: slot 15 empty)
-    const int trows = 16 / tpr;
     const int z0 = bz * C::BD, y0 = by * 2 * trows, x0 = bx * 2 * tpr;
     const int co0 = blockIdx.y * C::NT;
     const int nchunk = Cin / C::CK;
+
+    // A row m = a*32 + li is tile (dz = m >> 4, th, tw) and reads V row (dz + kd)*16 + tile = m + 16*kd.
+    // A V row holds the 8 channels of a chunk without padding; the two 16-byte halves of the rows of an odd
+    // halo plane are swapped, which spreads the 16 lanes that share an LDS cycle over all 64 banks (lanes li
+    // and li + 16 meet in one cycle and are 128 floats apart) and makes the staging writes conflict-free.
+    const int aoff0 = ph * 4 * C::PLANE + li * C::CK + 4 * (lh ^ ((li >> 4) & 1));   // kd even; + a*256 + kd*128 + pw*PLANE
+    const int aoff1 = aoff0 ^ 4;                                                        // kd odd
+    // this lane's B fragment inside a packed [64 co][8 ci] slice; slices of this wave: kd*16 + ph*4 + pw.
+    // Every vector instruction beside the fp32 matrix instructions costs matrix-pipe time (the two do not
+    // overlap on a SIMD), so the loop addresses global memory through buffer descriptors: per-lane offsets
+    // stay constant and everything that moves is scalar.
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(wp), 0, (int)(((long)gridDim.y * nchunk + 1) * C::TAPS * C::SLICE * 4), 0x00020000);
+    const unsigned wvo = ((ph * 4) * C::SLICE + (wn * 32 + li) * 8 + 4 * lh) * 4;
+    const int wso0 = (int)blockIdx.y * nchunk * C::TAPS * C::SLICE * 4;
+    constexpr int PD = C::PD;
+    float4 bring[PD];
+
+    // ---- raw halo image: the 8 channels of a chunk of every halo voxel, [voxel][8], zeros outside the
+    // volume.  Item i = p*512 + tid is half (i & 1) of voxel i >> 1: every wave fetches three 16-byte
+    // items per chunk with plain coalesced loads (pairs of lanes read 32 contiguous bytes) one chunk ahead
+    // and stores them ten taps later; the overlapping 4x4 patches are then cut out of LDS.
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x + (long)n * D * H * W * Cin), 0, D * H * W * Cin * 4, 0x00020000);
+    unsigned roff[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int i = p * C::NTHR + tid, v = i >> 1;
+        const int hx = v % BWP, hy = (v / BWP) % BHP, hz = v / (BWP * BHP);
+        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool ok = v < NV && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        roff[p] = ok ? (unsigned)((((gz * H + gy) * W + gx) * Cin + 4 * (i & 1)) * 4) : W2_OUTSIDE;
+    }
+    float4 raw[3];
+    auto load_raw = [&](int c0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) raw[p] = w2_bload(xrs, roff[p], c0 * 4);
+    };
+    auto store_raw = [&](float* img) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<float4*>(img + (p * C::NTHR + tid) * 4) = raw[p];
+    };
+
+    // ---- staging item of this lane: tile-row r of the 6 x 16 tiles, channel pair QI*h + qi in round h.
+    // (Two channels at a time, not four: the 16-voxel patch then takes 32 registers beside the 128
+    // accumulators instead of 64.)
+    constexpr int QI = 4 / ROUNDS, NSW = 96 * QI / 64;
+    const bool s_on = wave < NSW;
+    const int s_item = s_on ? wave * 64 + lane : 0;
+    const int s_qi = s_item % QI, s_r = s_item / QI;
+    const int s_hz = s_r >> 4, s_th = (s_r & 15) / tpr, s_tw = (s_r & 15) - s_th * tpr;
+    // the empty tile slot of a 15-tile plane reads patch 0 of its plane; its accumulator rows are never stored
+    const int rbase = ((s_hz * BHP + (s_th < trows ? 2 * s_th : 0)) * BWP + (s_th < trows ? 2 * s_tw : 0)) * C::CK + 2 * s_qi;
+    float2 patch[16];
+    auto read_patch = [&](const float* img, int h) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                patch[rr * 4 + c] = *reinterpret_cast<const float2*>(img + rbase + 2 * QI * h + (rr * BWP + c) * C::CK);
+    };
+    // The transform is cut into eight pieces that the multiply loop issues between its MFMA groups, so
+    // that the matrix pipe never waits for a long block of vector instructions: pieces 0..3 transform patch
+    // row 0..3 along W in place, pieces 4..7 finish column pw = 0..3 along H and write its four positions.
+    auto stage_piece = [&](int piece, int h, float* buf) {
+        if (piece < 4) {
+            const int rr = piece;
+            const float2 t0 = w2sub(patch[rr * 4 + 0], patch[rr * 4 + 2]);
+            const float2 t1 = w2add(patch[rr * 4 + 1], patch[rr * 4 + 2]);
+            const float2 t2 = w2sub(patch[rr * 4 + 2], patch[rr * 4 + 1]);
+            const float2 t3 = w2sub(patch[rr * 4 + 1], patch[rr * 4 + 3]);
+            patch[rr * 4 + 0] = t0; patch[rr * 4 + 1] = t1; patch[rr * 4 + 2] = t2; patch[rr * 4 + 3] = t3;
+        } else {
+            const int pw = piece - 4;
+            float* dst = buf + s_r * C::CK + ((2 * (QI * h + s_qi)) ^ (4 * (s_hz & 1))) + pw * C::PLANE;
+            *reinterpret_cast<float2*>(dst + 0 * 4 * C::PLANE) = w2sub(patch[0 * 4 + pw], patch[2 * 4 + pw]);
+            *reinterpret_cast<float2*>(dst + 1 * 4 * C::PLANE) = w2add(patch[1 * 4 + pw], patch[2 * 4 + pw]);
+            *reinterpret_cast<float2*>(dst + 2 * 4 * C::PLANE) = w2sub(patch[2 * 4 + pw], patch[1 * 4 + pw]);
+            *reinterpret_cast<float2*>(dst + 3 * 4 * C::PLANE) = w2sub(patch[1 * 4 + pw], patch[3 * 4 + pw]);
+        }
+    };
+
+    // ---- prologue: raw image 0 -> V buffer 0, raw image 1, the first weight fragments
+    load_raw(0);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) bring[i] = w2_bload(wrs, wvo, wso0 + ((i >> 2) * 16 + (i & 3)) * C::SLICE * 4);
+    static_assert(12 % PD == 0, "ring index must not depend on the chunk");
+    store_raw(rimg);
+    load_raw((nchunk > 1 ? 1 : 0) * C::CK);
+    SIV_STAMP(1);
+    __syncthreads();
+    if (s_on) {
+#pragma unroll
+        for (int h = 0; h < ROUNDS; ++h) {
+            read_patch(rimg, h);
+#pragma unroll
+            for (int piece = 0; piece < 8; ++piece) stage_piece(piece, h, lds);
+        }
+    }
+    store_raw(rimg + C::RAW_FLOATS);
+    __syncthreads();
+    SIV_STAMP(2);
 
     f32x16 acc[4][2];          // [pw][row tile]
 #pragma unroll
@@ -105,104 +230,13 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][a][r] = 0.f;
 
-    // A row m = a*32 + li is tile (dz = m >> 4, th, tw) and reads V row (dz + kd)*16 + tile = m + 16*kd.
-    // A V row holds the 8 channels of a chunk without padding; the two 16-byte halves of the rows of an odd
-    // halo plane are swapped, which spreads the 16 lanes that share an LDS cycle over all 64 banks (lanes li
-    // and li + 16 meet in one cycle and are 128 floats apart) and makes the staging writes conflict-free.
-    const int aoff0 = ph * 4 * C::PLANE + li * C::CK + 4 * (lh ^ ((li >> 4) & 1));   // kd even; + a*256 + kd*128 + pw*PLANE
-    const int aoff1 = aoff0 ^ 4;                                                        // kd odd
-    // this lane's B fragment inside a packed [64 co][8 ci] slice; slices of this wave: kd*16 + ph*4 + pw
-    const float* wlane = wp + ((long)blockIdx.y * nchunk * C::TAPS + ph * 4) * C::SLICE + (wn * 32 + li) * 8 + 4 * lh;
-    constexpr int PD = C::PD;
-    float4 bring[PD];
-
-    // staging item of this lane: (tile-row r of the 6 x 16 tiles, channel pair q of the 8-channel chunk);
-    // the 384 items are the lanes of waves 0..5.  (Two channels per item, not four: the 16-voxel patch
-    // then takes 32 registers beside the 128 accumulators instead of 64.)
-    const bool s_on = wave < 6;
-    const int s_item = s_on ? wave * 64 + lane : 0;
-    const int s_q = s_item & 3, s_r = s_item >> 2;
-    const int s_hz = s_r >> 4, s_th = (s_r & 15) / tpr, s_tw = (s_r & 15) - s_th * tpr;
-    unsigned pmask = 0;        // validity of the 16 patch voxels
-    const int pgz = z0 - 1 + s_hz, pgy = y0 - 1 + 2 * s_th, pgx = x0 - 1 + 2 * s_tw;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const bool ok = s_on && s_th < trows && pgz >= 0 && pgz < D && pgy + rr >= 0 && pgy + rr < H && pgx + c >= 0 && pgx + c < W;
-            pmask |= (unsigned)ok << (rr * 4 + c);
-        }
-    // Patch addresses = uniform base (sample, chunk) + a 32-bit per-lane byte offset that is rebuilt from
-    // one register for every chunk: sixteen hoisted 64-bit pointers would cost 32 registers.
-    const char* xs = reinterpret_cast<const char*>(x + (long)n * D * H * W * Cin);
-    const int pvox = (pgz * H + pgy) * W + pgx;                       // may lie outside; masked per voxel
-    const int pbyte0 = (pvox * Cin + 2 * s_q) * 4;
-    const int rowb = W * Cin * 4, colb = Cin * 4;
-    float2 patch[16];
-    auto load_patch = [&](int c0) {
-        int pb = pbyte0;
-        asm volatile("" : "+v"(pb));                                   // keep the offsets out of loop-invariant registers
-        const char* xb = xs + (long)c0 * 4;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int k = rr * 4 + c;
-                const unsigned off = ((pmask >> k) & 1) ? (unsigned)(pb + rr * rowb + c * colb) : (unsigned)(8 * s_q);
-                patch[k] = *reinterpret_cast<const float2*>(xb + off);  // out of volume: reads voxel 0
-            }
-    };
-    // The transform is cut into eight pieces that the multiply loop issues between the MFMA groups of
-    // its last six taps, so that the matrix pipe never waits for a long block of vector instructions:
-    // pieces 0..3 transform patch row 0..3 along W in place, pieces 4..7 finish column pw = 0..3 along H
-    // and write its four positions.
-    auto stage_piece = [&](int piece, float* buf) {
-        if (piece < 4) {
-            const int rr = piece;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (!((pmask >> (rr * 4 + c)) & 1)) patch[rr * 4 + c] = make_float2(0.f, 0.f);
-            const float2 t0 = w2sub(patch[rr * 4 + 0], patch[rr * 4 + 2]);
-            const float2 t1 = w2add(patch[rr * 4 + 1], patch[rr * 4 + 2]);
-            const float2 t2 = w2sub(patch[rr * 4 + 2], patch[rr * 4 + 1]);
-            const float2 t3 = w2sub(patch[rr * 4 + 1], patch[rr * 4 + 3]);
-            patch[rr * 4 + 0] = t0; patch[rr * 4 + 1] = t1; patch[rr * 4 + 2] = t2; patch[rr * 4 + 3] = t3;
-        } else {
-            const int pw = piece - 4;
-            float* dst = buf + s_r * C::CK + ((2 * s_q) ^ (4 * (s_hz & 1))) + pw * C::PLANE;
-            *reinterpret_cast<float2*>(dst + 0 * 4 * C::PLANE) = w2sub(patch[0 * 4 + pw], patch[2 * 4 + pw]);
-            *reinterpret_cast<float2*>(dst + 1 * 4 * C::PLANE) = w2add(patch[1 * 4 + pw], patch[2 * 4 + pw]);
-            *reinterpret_cast<float2*>(dst + 2 * 4 * C::PLANE) = w2sub(patch[2 * 4 + pw], patch[1 * 4 + pw]);
-            *reinterpret_cast<float2*>(dst + 3 * 4 * C::PLANE) = w2sub(patch[1 * 4 + pw], patch[3 * 4 + pw]);
-        }
-    };
-
-    // chunk 0 -> buffer 0, first weight fragments; the loop is entered with no load in flight
-    if (!(SIV_W2EXP & 128)) load_patch(0);
-#pragma unroll
-    for (int i = 0; i < PD; ++i) bring[i] = *reinterpret_cast<const float4*>(wlane + ((i >> 2) * 16 + (i & 3)) * C::SLICE);
-    static_assert(12 % PD == 0, "ring index must not depend on the chunk");
-#define SIV_PIN(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
-#pragma unroll
-    for (int i = 0; i < PD; ++i) SIV_PIN(bring[i]);
-#undef SIV_PIN
-    if (s_on) {
-#pragma unroll
-        for (int piece = 0; piece < 8; ++piece) stage_piece(piece, lds);
-    }
-    if (!(SIV_W2EXP & 17)) load_patch((nchunk > 1 ? 1 : 0) * C::CK);
-    SIV_STAMP(1);
-    __syncthreads();
-    SIV_STAMP(2);
-
     for (int cc = 0; cc < nchunk; ++cc) {
         const float* cur = lds + (cc & 1) * C::V_FLOATS;
         float* nxt = lds + ((cc + 1) & 1) * C::V_FLOATS;
+        const float* rcur = rimg + ((cc + 1) & 1) * C::RAW_FLOATS;     // raw image of chunk cc + 1
+        float* rnxt = rimg + (cc & 1) * C::RAW_FLOATS;                 // receives chunk cc + 2
         const bool more = cc + 1 < nchunk;
-        // every wave issues the patch loads (waves 6 and 7 re-read voxel 0 and drop it): with one
-        // instruction stream the compiler counts the loads that may stay in flight at each wait
-        // instead of assuming, at the first tap, the path that issued none
-        const float* wc = wlane + (long)cc * C::TAPS * C::SLICE;
+        const int wso = wso0 + cc * C::TAPS * C::SLICE * 4;
         float4 anext[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) anext[a] = *reinterpret_cast<const float4*>(cur + aoff0 + a * 256);
@@ -216,17 +250,14 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             {   // fragment of tap t + PD (running into the next chunk at the end of this one)
                 const int tn = t + PD;
                 const int sl = tn < 12 ? (tn >> 2) * 16 + (tn & 3) : C::TAPS + ((tn - 12) >> 2) * 16 + ((tn - 12) & 3);
-                if (!(SIV_W2EXP & 4)) bring[t % PD] = *reinterpret_cast<const float4*>(wc + sl * C::SLICE);
+                bring[t % PD] = w2_bload(wrs, wvo, wso + sl * C::SLICE * 4);
             }
             if (t + 1 < 12) {
                 const int t1 = t + 1;
                 const int tapoff = (t1 & 3) * C::PLANE + (t1 >> 2) * 128;
                 const int abase = (t1 >> 2) == 1 ? aoff1 : aoff0;
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    if (SIV_W2EXP & 8) asm volatile("" : "+v"(anext[a].x), "+v"(anext[a].y), "+v"(anext[a].z), "+v"(anext[a].w));
-                    else anext[a] = *reinterpret_cast<const float4*>(cur + abase + a * 256 + tapoff);
-                }
+                for (int a = 0; a < 2; ++a) anext[a] = *reinterpret_cast<const float4*>(cur + abase + a * 256 + tapoff);
             }
             __builtin_amdgcn_sched_barrier(0);
 #define SIV_W2STEP(F)                                                                       \
@@ -238,23 +269,30 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             SIV_W2STEP(w)
 #undef SIV_W2STEP
             __builtin_amdgcn_sched_barrier(0);
-            // the patch loads get half a chunk before their first use (rows 0..3 at taps 6 and 7)
-            if (more && s_on && !(SIV_W2EXP & 33)) {
-                if (t == 6) { stage_piece(0, nxt); stage_piece(1, nxt); }
-                if (t == 7) { stage_piece(2, nxt); stage_piece(3, nxt); }
-                if (t >= 8) stage_piece(t - 4, nxt);
+            // the raw image of the chunk after next: fetched now, stored at tap 10 (every wave)
+            if (t == 0) load_raw((cc + 2 < nchunk ? cc + 2 : cc) * C::CK);
+            if (t == 10) store_raw(rnxt);
+            // chunk cc + 1: patch reads one tap ahead of the first piece, two pieces per tap
+            if (more && s_on) {
+                if (ROUNDS == 2) {
+                    if (t == 0) read_patch(rcur, 0);
+                    if (t >= 1 && t <= 4) { stage_piece(2 * t - 2, 0, nxt); stage_piece(2 * t - 1, 0, nxt); }
+                    if (t == 5) read_patch(rcur, 1);
+                    if (t >= 6 && t <= 9) { stage_piece(2 * t - 12, 1, nxt); stage_piece(2 * t - 11, 1, nxt); }
+                } else {
+                    if (t == 5) read_patch(rcur, 0);
+                    if (t == 6) { stage_piece(0, 0, nxt); stage_piece(1, 0, nxt); }
+                    if (t == 7) { stage_piece(2, 0, nxt); stage_piece(3, 0, nxt); }
+                    if (t >= 8) stage_piece(t - 4, 0, nxt);
+                }
             }
         }
-        // the patch of the chunk after next goes out right behind the last pieces of this one: its
-        // issue overlaps the wait at the barrier and it has a chunk and a half to arrive
-        if (!(SIV_W2EXP & 17)) load_patch((cc + 2 < nchunk ? cc + 2 : cc) * C::CK);
         SIV_STAMP(3 + 2 * cc);
-        if (!(SIV_W2EXP & 2)) __syncthreads();
+        __syncthreads();
         SIV_STAMP(4 + 2 * cc);
     }
 
     // ---- output transform and store ----
-    if ((SIV_W2EXP & 64) && acc[0][0][0] != 123.f) return;
     // along W on the accumulators: Z[ow] = sum_pw At[ow][pw] M[ph][pw]
     const int cq = lane & 7;
     const int co = co0 + wn * 32 + 4 * cq;
@@ -399,13 +437,14 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
         set_error("conv3d_k3(winograd 2-D): too many bricks");
         return SIV_EINVAL;
     }
-    if (hipFuncSetAttribute((const void*)k3_fwd_wino2d, hipFuncAttributeMaxDynamicSharedMemorySize,
+    auto kern = tpr == 5 ? k3_fwd_wino2d<5, SIV_W2ROUNDS> : k3_fwd_wino2d<4, SIV_W2ROUNDS>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)W2Cfg::LDS_BYTES) != hipSuccess) {
         set_error("conv3d_k3(winograd 2-D): cannot reserve %zu bytes of LDS", W2Cfg::LDS_BYTES);
         return SIV_EHIP;
     }
-    k3_fwd_wino2d<<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 512, W2Cfg::LDS_BYTES, s>>>(
-        x, wpk, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part, tpr);
+    kern<<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 512, W2Cfg::LDS_BYTES, s>>>(
+        x, wpk, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part);
     SIV_CHECK_LAUNCH("conv3d_k3(winograd 2-D)");
     return SIV_OK;
 }
