@@ -983,7 +983,9 @@ struct UdCfg {
     static constexpr int V_FLOATS = LBD * HH * PITCH;
     static constexpr int TAPS = 16, SLICE = NT * 8;
     static constexpr int EPI_STRIDE = 40, EPI_FLOATS = 32 * EPI_STRIDE;
-    static constexpr size_t LDS_BYTES = (size_t)V_FLOATS * sizeof(float);
+    static constexpr int SLACK = PITCH + HWH * CKP;         // what the box sums of the last halo row touch behind the image
+    static constexpr int PARK = NH > 8 ? 4 : 0;             // load offsets per thread parked in LDS instead of registers
+    static constexpr size_t LDS_BYTES = (size_t)(V_FLOATS + SLACK + PARK * NTHR) * sizeof(float);
     static_assert(PITCH >= 2 * HWH * CKP && PITCH % 32 == 16, "row pitch");
     static_assert(M <= 256 && M > 224, "four row tiles per wave, two waves along M");
     static_assert(V_FLOATS >= 4 * EPI_FLOATS, "epilogue tiles fit");
@@ -996,8 +998,24 @@ struct UdCfg {
 //   sum_u q[u] dy[2j+u] = w0 (dy[2j+1] + dy[2j+2]) + w1 (dy[2j] + dy[2j+1]) + w2 (dy[2j-1] + dy[2j]),
 // so a tap (kh, kw) multiplies the 2x2 in-plane box sum of dy that starts at (2j+1-kh, 2j+1-kw): 9 taps
 // per staged plane instead of 16 (36 instead of 64 per low-resolution voxel).  The box sums are formed
-// from four LDS reads while the operand is fetched; staging, layout and epilogue are unchanged.  Only
-// the order of the fp32 additions differs from the 16-tap form.
+// once per step, in place: the thread that staged voxel (y, x) adds its three neighbours out of the raw
+// image and writes the sum back where the voxel was (vector instructions do not overlap fp32 matrix
+// instructions on a SIMD, so summing per tap and row tile -- 432 additions per wave and step -- cost a
+// third of the step).  Layout and epilogue are unchanged; only the order of the fp32 additions differs
+// from the 16-tap form.
+// SIV_UDSTAMP (diagnostic build only, tools/ubench/up_dgrad_stamps.hip): lane 0 of every wave of the first
+// blocks records the shader clock around the phases of steps 8..11 into a buffer nothing else reads.
+#ifdef SIV_UDSTAMP
+__device__ unsigned long long ud_stamps[4096 * 4 * 32];
+#define SIV_UDS(i)                                                                                           \
+    do {                                                                                                     \
+        if (lane == 0 && blockIdx.x < 4096 && step >= 8 && step < 12)                                        \
+            ud_stamps[((long)blockIdx.x * 4 + wave) * 32 + (step - 8) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define SIV_UDS(i)
+#endif
+
 template <int LBD, int LBH, int LBW, bool SPLIT, bool BOX = false>
 __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ dy,
                                                       const void* __restrict__ wpv,
@@ -1021,12 +1039,6 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
     const int ci0 = blockIdx.y * C::NT;
     const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
     const int nstep = (Cout / C::CK) * 4;                       // (chunk, u along D)
-
-    f32x16 acc[C::AM];
-#pragma unroll
-    for (int a = 0; a < C::AM; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
     // LDS offset of this lane's A row for tap (u_h, u_w) = (-1, -1); with SPLIT three of them, one per
     // A operand (pieces h|h, m|h, l|m by lane half)
@@ -1058,6 +1070,21 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
     int hoff[C::NH], hdst[C::NH];
     unsigned hmask = 0, curmask = 0;
     int hpz[C::NH];
+    // BOX: the loads go through a buffer descriptor of sample n.  A voxel outside the sample in z lands
+    // below or beyond the descriptor's range by itself, one outside in y or x is sent there (UP_OUTSIDE),
+    // and either reads zeros: no masks, no selects, one 32-bit addition per load.
+    const __amdgpu_buffer_rsrc_t drs = buf_rsrc(dy + (long)n * D * H * W * Cout, BOX ? (long)D * H * W * Cout * 4 : 0);
+    const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(wpv, BOX ? (long)gridDim.y * nstep * 9 * C::SLICE * 4 : 0);
+    const unsigned wvo = ((wn * 32 + li) * 8 + 4 * lh) * 4;
+    const int wso0 = (int)blockIdx.y * nstep * 9 * C::SLICE * 4;
+    auto wstep = [&](int step) {    // BOX: byte offset of the nine slices of a step
+        return wso0 + step * 9 * C::SLICE * 4;
+    };
+    constexpr unsigned UP_OUTSIDE = 0xC0000000u;
+    // BOX: LDS offset of the voxel to the right minus this voxel's.  Voxel hv = (tid >> 1) + 128 i and the
+    // halo row length is even, so the parity of the column is the same for every item of a thread.
+    static_assert(C::HWF % 2 == 0 && C::NTHR % 4 == 0, "column parity per thread");
+    const int hnx = ((tid >> 1) & 1) ? (1 - C::HWH) * C::CKP : C::HWH * C::CKP;
 #pragma unroll
     for (int i = 0; i < C::NH; ++i) {
         const int idx = tid + C::NTHR * i;
@@ -1065,14 +1092,39 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
         const int hx = hv % C::HWF, hy = (hv / C::HWF) % C::HH, pz = hv / (C::HWF * C::HH);
         const int gy = 2 * y0 - 1 + hy, gx = 2 * x0 - 1 + hx;
         const bool ok = hv < C::HV && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        hoff[i] = ok ? ((2 * pz * H + (hy - 1)) * W + (hx - 1)) * Cout + 4 * q : 0;
-        hpz[i] = ok ? 2 * (z0 + pz) : -4;       // high-resolution plane for u = 0 (-4: never valid)
+        if constexpr (BOX) {
+            hoff[i] = ok ? (int)((((2 * (z0 + pz) * H + gy) * W + gx) * Cout + 4 * q) * 4) : (int)UP_OUTSIDE;
+            hpz[i] = 0;
+        } else {
+            hoff[i] = ok ? ((2 * pz * H + (hy - 1)) * W + (hx - 1)) * Cout + 4 * q : 0;
+            hpz[i] = ok ? 2 * (z0 + pz) : -4;       // high-resolution plane for u = 0 (-4: never valid)
+        }
         hdst[i] = (pz * C::HH + hy) * C::PITCH + ((hx & 1) * C::HWH + (hx >> 1)) * C::CKP + (SPLIT ? 2 : 4) * q;
         hmask |= (unsigned)(hv < C::HV) << i;
     }
+    // BOX with eleven items per thread: the offsets of the last four live in LDS (one 16-byte read per step);
+    // in registers they were spilled to scratch memory and reloaded in front of every step's loads.
+    constexpr int NHR = BOX ? C::NH - C::PARK : C::NH;
+    int* const park = reinterpret_cast<int*>(lds + C::V_FLOATS + C::SLACK) + 4 * tid;
+    if constexpr (BOX && C::PARK > 0)
+        *reinterpret_cast<int4*>(park) = make_int4(hoff[NHR], hoff[NHR + 1], hoff[NHR + 2], hoff[NHR + 3]);
     auto load_halo = [&](int step) {
         const int c0 = (step >> 2) * C::CK, u = (step & 3) - 1;
         unsigned mk = 0;
+        if constexpr (BOX) {
+            const int delta = (u * H * W * Cout + c0) * 4;
+            int4 pk = make_int4(0, 0, 0, 0);
+            if constexpr (C::PARK > 0) pk = *reinterpret_cast<const int4*>(park);
+#pragma unroll
+            for (int i = 0; i < NHR; ++i) hreg[i] = buf_load16(drs, (unsigned)(hoff[i] + delta), 0);
+            if constexpr (C::PARK > 0) {
+                hreg[NHR + 0] = buf_load16(drs, (unsigned)(pk.x + delta), 0);
+                hreg[NHR + 1] = buf_load16(drs, (unsigned)(pk.y + delta), 0);
+                hreg[NHR + 2] = buf_load16(drs, (unsigned)(pk.z + delta), 0);
+                hreg[NHR + 3] = buf_load16(drs, (unsigned)(pk.w + delta), 0);
+            }
+            return ~0u;
+        }
 #pragma unroll
         for (int i = 0; i < C::NH; ++i) {
             const int gz = hpz[i] + u;
@@ -1090,6 +1142,8 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
         if constexpr (SPLIT) {
             bxr[i] = wlq[i * 256];
             byr[i] = wlq[i * 256 + 128];
+        } else if constexpr (BOX) {
+            bring[i] = buf_load16(wrs, wvo, wstep(0) + i * C::SLICE * 4);
         } else {
             bring[i] = *reinterpret_cast<const float4*>(wlane + i * C::SLICE);
         }
@@ -1102,9 +1156,17 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
     }
 #undef SIV_PIN
 
+    f32x16 acc[C::AM];
+#pragma unroll
+    for (int a = 0; a < C::AM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
     for (int step = 0; step < nstep; ++step) {
         curmask = nextmask;
+        SIV_UDS(0);
         __syncthreads();  // previous step's MFMAs are done with the planes
+        SIV_UDS(1);
 #pragma unroll
         for (int i = 0; i < C::NH; ++i) {
             if (!((curmask >> i) & 1)) hreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1122,7 +1184,37 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
             }
         }
         __syncthreads();
+        SIV_UDS(2);
+        if constexpr (BOX) {
+            // raw image -> box image, in place: this voxel + right + below + below right
+#pragma unroll
+            for (int i = 0; i < C::NH; ++i) {
+                if ((hmask >> i) & 1) {
+                    // (the last row and column of the halo have no box of their own: what they add up --
+                    // the first row of the next plane, the slack row behind the image, column 1 -- is
+                    // never read)
+                    const float* d = lds + hdst[i];
+                    const float4 r1 = *reinterpret_cast<const float4*>(d + hnx);
+                    const float4 r2 = *reinterpret_cast<const float4*>(d + C::PITCH);
+                    const float4 r3 = *reinterpret_cast<const float4*>(d + C::PITCH + hnx);
+                    hreg[i].x = (hreg[i].x + r1.x) + (r2.x + r3.x);
+                    hreg[i].y = (hreg[i].y + r1.y) + (r2.y + r3.y);
+                    hreg[i].z = (hreg[i].z + r1.z) + (r2.z + r3.z);
+                    hreg[i].w = (hreg[i].w + r1.w) + (r2.w + r3.w);
+                }
+                if (i % 2 == 1) __builtin_amdgcn_sched_barrier(0);     // two items' reads in flight, not all
+            }
+            SIV_UDS(3);
+            __syncthreads();  // every neighbour has been read
+            SIV_UDS(4);
+#pragma unroll
+            for (int i = 0; i < C::NH; ++i)
+                if ((hmask >> i) & 1) *reinterpret_cast<float4*>(lds + hdst[i]) = hreg[i];
+            __syncthreads();
+        }
+        SIV_UDS(5);
         nextmask = load_halo(step + 1 < nstep ? step + 1 : step);
+        SIV_UDS(6);
         if constexpr (SPLIT) {
             const uint4* wq = wlq + (long)step * C::TAPS * 256;
             bf16x8 n1, n2, n3;            // A operands, read one (tap, row tile) unit ahead of their MFMAs
@@ -1157,55 +1249,34 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
         }
         const float* wc = wlane + (long)step * NTAP * C::SLICE;
         if constexpr (BOX) {
-            // raw voxels (row e_h + i, column e_w + j), i, j in {0, 1}, of the W-parity-split image
-            auto boxoff = [&](int t, int i, int j) {
-                const int eh = t / 3 + i, px = t % 3 + j;
+            // the box that starts at row e_h, column e_w of the W-parity-split image
+            auto boxoff = [&](int t) {
+                const int eh = t / 3, px = t % 3;
                 return eh * C::PITCH + ((px & 1) * C::HWH + (px >> 1)) * C::CKP;
             };
-            // The operand of tap t + 1 is gathered while tap t multiplies: row tile a's four reads go
-            // out before matrix group a and are summed behind it (16 registers in flight, not 64).
-            float4 anext[C::AM], raw[4];
-            auto fetch = [&](int t, int a) {
+            const int wso = wstep(step);
+            // Row tile a's four matrix instructions run back to back (the accumulator is ready again when
+            // the next one issues), so its operand register is free behind them and takes tap t + 1 at
+            // once: 16 operand registers instead of 32.
+            float4 av[C::AM];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    raw[q] = *reinterpret_cast<const float4*>(lds + aoff[a] + boxoff(t, q >> 1, q & 1));
-            };
-            auto boxsum = [&](int a) {
-                anext[a].x = (raw[0].x + raw[1].x) + (raw[2].x + raw[3].x);
-                anext[a].y = (raw[0].y + raw[1].y) + (raw[2].y + raw[3].y);
-                anext[a].z = (raw[0].z + raw[1].z) + (raw[2].z + raw[3].z);
-                anext[a].w = (raw[0].w + raw[1].w) + (raw[2].w + raw[3].w);
-            };
-#pragma unroll
-            for (int a = 0; a < C::AM; ++a) {
-                fetch(0, a);
-                boxsum(a);
-            }
+            for (int a = 0; a < C::AM; ++a) av[a] = *reinterpret_cast<const float4*>(lds + aoff[a] + boxoff(0));
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                float4 av[C::AM];
                 const float4 bv = bring[t % PD];
+                bring[t % PD] = buf_load16(wrs, wvo, wso + (t + PD) * C::SLICE * 4);    // runs into the next step's slices
 #pragma unroll
-                for (int a = 0; a < C::AM; ++a) av[a] = anext[a];
-                bring[t % PD] = *reinterpret_cast<const float4*>(wc + (t + PD) * C::SLICE);
-                const bool nx = t + 1 < 9;
-                if (nx) fetch(t + 1, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#define SIV_BSTEP(F, A)                                                                     \
-    _Pragma("unroll") for (int a = 0; a < C::AM; ++a)                                       \
-        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].F, bv.F, acc[a], 0, 0, 0);      \
-    __builtin_amdgcn_sched_barrier(0);                                                      \
-    if (nx) {                                                                               \
-        boxsum(A);                                                                          \
-        if (A + 1 < C::AM) fetch(t + 1, A + 1);                                             \
-    }                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);
-                SIV_BSTEP(x, 0)
-                SIV_BSTEP(y, 1)
-                SIV_BSTEP(z, 2)
-                SIV_BSTEP(w, 3)
-#undef SIV_BSTEP
+                for (int a = 0; a < C::AM; ++a) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].x, bv.x, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].y, bv.y, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].z, bv.z, acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].w, bv.w, acc[a], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 1 < 9) av[a] = *reinterpret_cast<const float4*>(lds + aoff[a] + boxoff(t + 1));
+                }
             }
+            SIV_UDS(7);
             continue;
         }
         float4 anext[C::AM];

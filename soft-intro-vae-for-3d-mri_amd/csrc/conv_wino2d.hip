@@ -45,15 +45,6 @@ __device__ unsigned long long w2_stamps[2048 * 8 * 32];
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float w2f4 __attribute__((ext_vector_type(4)));
-
-// 16 bytes through a buffer descriptor: byte offset = per-lane voff + wave-uniform soff (+ an immediate the
-// compiler folds); no 64-bit address arithmetic on the vector ALU, and a lane whose voff lies beyond the
-// descriptor's size reads zeros without touching memory.
-__device__ __forceinline__ float4 w2_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
-    const w2f4 f = __builtin_bit_cast(w2f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-    return make_float4(f.x, f.y, f.z, f.w);
-}
 constexpr unsigned W2_OUTSIDE = 0x80000000u;      // beyond any sample (the launcher keeps samples below 2 GiB)
 
 struct W2Cfg {
@@ -130,8 +121,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     // Every vector instruction beside the fp32 matrix instructions costs matrix-pipe time (the two do not
     // overlap on a SIMD), so the loop addresses global memory through buffer descriptors: per-lane offsets
     // stay constant and everything that moves is scalar.
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(wp), 0, (int)(((long)gridDim.y * nchunk + 1) * C::TAPS * C::SLICE * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(wp, ((long)gridDim.y * nchunk + 1) * C::TAPS * C::SLICE * 4);
     const unsigned wvo = ((ph * 4) * C::SLICE + (wn * 32 + li) * 8 + 4 * lh) * 4;
     const int wso0 = (int)blockIdx.y * nchunk * C::TAPS * C::SLICE * 4;
     constexpr int PD = C::PD;
@@ -141,8 +131,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     // volume.  Item i = p*512 + tid is half (i & 1) of voxel i >> 1: every wave fetches three 16-byte
     // items per chunk with plain coalesced loads (pairs of lanes read 32 contiguous bytes) one chunk ahead
     // and stores them ten taps later; the overlapping 4x4 patches are then cut out of LDS.
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(x + (long)n * D * H * W * Cin), 0, D * H * W * Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = buf_rsrc(x + (long)n * D * H * W * Cin, (long)D * H * W * Cin * 4);
     unsigned roff[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -155,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     float4 raw[3];
     auto load_raw = [&](int c0) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) raw[p] = w2_bload(xrs, roff[p], c0 * 4);
+        for (int p = 0; p < 3; ++p) raw[p] = buf_load16(xrs, roff[p], c0 * 4);
     };
     auto store_raw = [&](float* img) {
 #pragma unroll
@@ -204,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     // ---- prologue: raw image 0 -> V buffer 0, raw image 1, the first weight fragments
     load_raw(0);
 #pragma unroll
-    for (int i = 0; i < PD; ++i) bring[i] = w2_bload(wrs, wvo, wso0 + ((i >> 2) * 16 + (i & 3)) * C::SLICE * 4);
+    for (int i = 0; i < PD; ++i) bring[i] = buf_load16(wrs, wvo, wso0 + ((i >> 2) * 16 + (i & 3)) * C::SLICE * 4);
     static_assert(12 % PD == 0, "ring index must not depend on the chunk");
     store_raw(rimg);
     load_raw((nchunk > 1 ? 1 : 0) * C::CK);
@@ -250,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             {   // fragment of tap t + PD (running into the next chunk at the end of this one)
                 const int tn = t + PD;
                 const int sl = tn < 12 ? (tn >> 2) * 16 + (tn & 3) : C::TAPS + ((tn - 12) >> 2) * 16 + ((tn - 12) & 3);
-                bring[t % PD] = w2_bload(wrs, wvo, wso + sl * C::SLICE * 4);
+                bring[t % PD] = buf_load16(wrs, wvo, wso + sl * C::SLICE * 4);
             }
             if (t + 1 < 12) {
                 const int t1 = t + 1;

@@ -46,6 +46,21 @@ enum PackFamily { PF_MFMA = 1, PF_WINO, PF_WINO_B3, PF_WINO2D, PF_UP_PROD, PF_UP
 void* pack_slot(const void* w, int family, int variant, int flip, int Cin, int Cout, size_t bytes, void* ws,
                 bool* need_pack);
 
+// 16 bytes through a buffer descriptor: byte offset = per-lane voff + wave-uniform soff (+ an immediate the
+// compiler folds).  No 64-bit address arithmetic on the vector ALU, and a lane whose voff lies beyond the
+// descriptor's size reads zeros without touching memory (the range check looks at voff and the immediate,
+// so whatever decides validity belongs in voff).
+#ifdef __HIPCC__
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    const f32x4_t f = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+#endif
+
 // BatchNorm of the layer in front, for kernels that apply it (and the LeakyReLU behind it) to their
 // operand instead of reading an activated tensor
 struct BnPrologue {
