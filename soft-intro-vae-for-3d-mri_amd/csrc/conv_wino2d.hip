@@ -15,15 +15,16 @@
 //
 // The transformed input V[pos][plane][tile][ci] of one 8-channel chunk takes 48 KB of LDS and the epilogue
 // 144 KB, so one block runs per CU and nothing else would cover its barriers: V is double buffered.  While the waves multiply
-// chunk c out of one buffer, six of the eight waves transform the 4x4 patches of chunk c+1 (fetched into
-// registers at the end of chunk c-1; overlapping patches: L1/L2 hits) and fill the other buffer; one barrier
-// per chunk.  The output transform along W is done on the accumulators, the one along H needs the four
+// chunk c out of one buffer, six of the eight waves cut the 4x4 patches of chunk c+1 out of a raw halo image
+// in LDS (fetched one chunk earlier with coalesced 16-byte loads), transform them and fill the other buffer;
+// one barrier per chunk.  The output transform along W is done on the accumulators, the one along H needs the four
 // waves ph = 0..3 and goes through LDS together with the transposition for 16-byte stores.
 #include "siv_common.h"
 
-// SIV_W2EXP: timing-only ablation mask (never set in the library build): 1 = no staging of the next
-// chunk (16 = no patch loads only, 32 = no transform / LDS writes only), 2 = no barrier per chunk,
-// 4 = no weight-fragment loads, 8 = no LDS fragment reads, 64 = no epilogue, 128 = no first patch loads
+// SIV_W2EXP: timing-only ablation mask (never set in the library build; results are wrong with it):
+// 1 = no staging of the next chunk, 2 = transform without the V writes, 4 = no patch reads.
+// Measured with tools/ubench/wino2d_stamps (64 -> 64 @80x96x80, cycles per chunk, floor 12288):
+// full 14165, no patch reads 13728, no staging 12820; the SIMDs that hold two staging waves set the pace.
 #ifndef SIV_W2EXP
 #define SIV_W2EXP 0
 #endif
@@ -45,6 +46,7 @@ __device__ unsigned long long w2_stamps[2048 * 8 * 32];
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));    // two channels per lane: one packed add per pair
 constexpr unsigned W2_OUTSIDE = 0x80000000u;      // beyond any sample (the launcher keeps samples below 2 GiB)
 
 struct W2Cfg {
@@ -73,6 +75,11 @@ __device__ __forceinline__ float4 w2add(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float2 w2sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 w2add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 
+// CUs of the device (gfx950: 256): the stride between a block and the one that follows it on its CU; 0 = no
+// warming of the next block's first halo images
+#ifndef SIV_W2_CUS
+#define SIV_W2_CUS 256
+#endif
 #ifndef SIV_W2ROUNDS
 #define SIV_W2ROUNDS 1
 #endif
@@ -101,13 +108,16 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     const int ph = wave & 3, wn = wave >> 2;
     SIV_STAMP(0);
 
-    int b = blockIdx.x;
-    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
-    const int bx = b % nbw; b /= nbw;
-    const int by = b % nbh; b /= nbh;
-    const int bz = b % nbd;
-    const int n = b / nbd;
-    const int z0 = bz * C::BD, y0 = by * 2 * trows, x0 = bx * 2 * tpr;
+    // brick of a block index: each XCD (blockIdx.x mod 8) walks a contiguous eighth of the bricks
+    auto brick_of = [&](int b, int& bn, int& bz0, int& by0, int& bx0) {
+        if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+        const int bx = b % nbw; b /= nbw;
+        const int by = b % nbh; b /= nbh;
+        bz0 = (b % nbd) * C::BD; by0 = by * 2 * trows; bx0 = bx * 2 * tpr;
+        bn = b / nbd;
+    };
+    int n, z0, y0, x0;
+    brick_of(blockIdx.x, n, z0, y0, x0);
     const int co0 = blockIdx.y * C::NT;
     const int nchunk = Cin / C::CK;
 
@@ -133,18 +143,34 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     // and stores them ten taps later; the overlapping 4x4 patches are then cut out of LDS.
     const __amdgpu_buffer_rsrc_t xrs = buf_rsrc(x + (long)n * D * H * W * Cin, (long)D * H * W * Cin * 4);
     unsigned roff[3];
+    auto halo_offsets = [&](int bz0, int by0, int bx0) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const int i = p * C::NTHR + tid, v = i >> 1;
-        const int hx = v % BWP, hy = (v / BWP) % BHP, hz = v / (BWP * BHP);
-        const int gz = z0 - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        const bool ok = v < NV && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        roff[p] = ok ? (unsigned)((((gz * H + gy) * W + gx) * Cin + 4 * (i & 1)) * 4) : W2_OUTSIDE;
-    }
+        for (int p = 0; p < 3; ++p) {
+            const int i = p * C::NTHR + tid, v = i >> 1;
+            const int hx = v % BWP, hy = (v / BWP) % BHP, hz = v / (BWP * BHP);
+            const int gz = bz0 - 1 + hz, gy = by0 - 1 + hy, gx = bx0 - 1 + hx;
+            const bool ok = v < NV && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            roff[p] = ok ? (unsigned)((((gz * H + gy) * W + gx) * Cin + 4 * (i & 1)) * 4) : W2_OUTSIDE;
+        }
+    };
+    halo_offsets(z0, y0, x0);
     float4 raw[3];
     auto load_raw = [&](int c0) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) raw[p] = buf_load16(xrs, roff[p], c0 * 4);
+    };
+    // The block that follows this one on its CU (blocks start in index order, one per CU) waits for its
+    // first two halo images with nothing to do.  The last two chunks of this block have no image left to
+    // fetch for themselves, so their fetch slots touch that block's first two images instead: the data
+    // lands in the L2 of the XCD both blocks run on (the stride is a multiple of 8).
+    const long lin_next = (long)blockIdx.y * gridDim.x + blockIdx.x + SIV_W2_CUS;
+    const bool warm = SIV_W2_CUS > 0 && nchunk >= 3 && lin_next < (long)gridDim.x * gridDim.y;
+    int nn = n, nz0 = z0, ny0 = y0, nx0 = x0;
+    if (warm) brick_of((int)(lin_next % gridDim.x), nn, nz0, ny0, nx0);
+    const __amdgpu_buffer_rsrc_t xrs_next = buf_rsrc(x + (long)nn * D * H * W * Cin, (long)D * H * W * Cin * 4);
+    auto load_raw_next = [&](int c0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) raw[p] = buf_load16(xrs_next, roff[p], c0 * 4);
     };
     auto store_raw = [&](float* img) {
 #pragma unroll
@@ -155,19 +181,20 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     // (Two channels at a time, not four: the 16-voxel patch then takes 32 registers beside the 128
     // accumulators instead of 64.)
     constexpr int QI = 4 / ROUNDS, NSW = 96 * QI / 64;
-    const bool s_on = wave < NSW;
+    const bool s_on = (SIV_W2EXP & 1) ? false : wave < NSW;
     const int s_item = s_on ? wave * 64 + lane : 0;
     const int s_qi = s_item % QI, s_r = s_item / QI;
     const int s_hz = s_r >> 4, s_th = (s_r & 15) / tpr, s_tw = (s_r & 15) - s_th * tpr;
     // the empty tile slot of a 15-tile plane reads patch 0 of its plane; its accumulator rows are never stored
     const int rbase = ((s_hz * BHP + (s_th < trows ? 2 * s_th : 0)) * BWP + (s_th < trows ? 2 * s_tw : 0)) * C::CK + 2 * s_qi;
-    float2 patch[16];
+    f32x2 patch[16];
     auto read_patch = [&](const float* img, int h) {
+        if (SIV_W2EXP & 4) return;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                patch[rr * 4 + c] = *reinterpret_cast<const float2*>(img + rbase + 2 * QI * h + (rr * BWP + c) * C::CK);
+                patch[rr * 4 + c] = *reinterpret_cast<const f32x2*>(img + rbase + 2 * QI * h + (rr * BWP + c) * C::CK);
     };
     // The transform is cut into eight pieces that the multiply loop issues between its MFMA groups, so
     // that the matrix pipe never waits for a long block of vector instructions: pieces 0..3 transform patch
@@ -175,28 +202,37 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     auto stage_piece = [&](int piece, int h, float* buf) {
         if (piece < 4) {
             const int rr = piece;
-            const float2 t0 = w2sub(patch[rr * 4 + 0], patch[rr * 4 + 2]);
-            const float2 t1 = w2add(patch[rr * 4 + 1], patch[rr * 4 + 2]);
-            const float2 t2 = w2sub(patch[rr * 4 + 2], patch[rr * 4 + 1]);
-            const float2 t3 = w2sub(patch[rr * 4 + 1], patch[rr * 4 + 3]);
+            const f32x2 t0 = patch[rr * 4 + 0] - patch[rr * 4 + 2];
+            const f32x2 t1 = patch[rr * 4 + 1] + patch[rr * 4 + 2];
+            const f32x2 t2 = patch[rr * 4 + 2] - patch[rr * 4 + 1];
+            const f32x2 t3 = patch[rr * 4 + 1] - patch[rr * 4 + 3];
             patch[rr * 4 + 0] = t0; patch[rr * 4 + 1] = t1; patch[rr * 4 + 2] = t2; patch[rr * 4 + 3] = t3;
         } else {
             const int pw = piece - 4;
+            if (SIV_W2EXP & 2) { patch[pw] = (patch[0 * 4 + pw] - patch[2 * 4 + pw]) + (patch[1 * 4 + pw] + patch[2 * 4 + pw]) + (patch[2 * 4 + pw] - patch[1 * 4 + pw]) + (patch[1 * 4 + pw] - patch[3 * 4 + pw]); return; }
             float* dst = buf + s_r * C::CK + ((2 * (QI * h + s_qi)) ^ (4 * (s_hz & 1))) + pw * C::PLANE;
-            *reinterpret_cast<float2*>(dst + 0 * 4 * C::PLANE) = w2sub(patch[0 * 4 + pw], patch[2 * 4 + pw]);
-            *reinterpret_cast<float2*>(dst + 1 * 4 * C::PLANE) = w2add(patch[1 * 4 + pw], patch[2 * 4 + pw]);
-            *reinterpret_cast<float2*>(dst + 2 * 4 * C::PLANE) = w2sub(patch[2 * 4 + pw], patch[1 * 4 + pw]);
-            *reinterpret_cast<float2*>(dst + 3 * 4 * C::PLANE) = w2sub(patch[1 * 4 + pw], patch[3 * 4 + pw]);
+            *reinterpret_cast<f32x2*>(dst + 0 * 4 * C::PLANE) = patch[0 * 4 + pw] - patch[2 * 4 + pw];
+            *reinterpret_cast<f32x2*>(dst + 1 * 4 * C::PLANE) = patch[1 * 4 + pw] + patch[2 * 4 + pw];
+            *reinterpret_cast<f32x2*>(dst + 2 * 4 * C::PLANE) = patch[2 * 4 + pw] - patch[1 * 4 + pw];
+            *reinterpret_cast<f32x2*>(dst + 3 * 4 * C::PLANE) = patch[1 * 4 + pw] - patch[3 * 4 + pw];
         }
     };
 
     // ---- prologue: raw image 0 -> V buffer 0, raw image 1, the first weight fragments
+    // (both images are requested before either is waited for)
     load_raw(0);
+    {
+        float4 raw1[3];
 #pragma unroll
-    for (int i = 0; i < PD; ++i) bring[i] = buf_load16(wrs, wvo, wso0 + ((i >> 2) * 16 + (i & 3)) * C::SLICE * 4);
-    static_assert(12 % PD == 0, "ring index must not depend on the chunk");
-    store_raw(rimg);
-    load_raw((nchunk > 1 ? 1 : 0) * C::CK);
+        for (int p = 0; p < 3; ++p) raw1[p] = buf_load16(xrs, roff[p], (nchunk > 1 ? 1 : 0) * C::CK * 4);
+#pragma unroll
+        for (int i = 0; i < PD; ++i) bring[i] = buf_load16(wrs, wvo, wso0 + ((i >> 2) * 16 + (i & 3)) * C::SLICE * 4);
+        static_assert(12 % PD == 0, "ring index must not depend on the chunk");
+        store_raw(rimg);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) raw[p] = raw1[p];
+    }
+    store_raw(rimg + C::RAW_FLOATS);
     SIV_STAMP(1);
     __syncthreads();
     if (s_on) {
@@ -207,7 +243,6 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
             for (int piece = 0; piece < 8; ++piece) stage_piece(piece, h, lds);
         }
     }
-    store_raw(rimg + C::RAW_FLOATS);
     __syncthreads();
     SIV_STAMP(2);
 
@@ -259,8 +294,13 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
 #undef SIV_W2STEP
             __builtin_amdgcn_sched_barrier(0);
             // the raw image of the chunk after next: fetched now, stored at tap 10 (every wave)
-            if (t == 0) load_raw((cc + 2 < nchunk ? cc + 2 : cc) * C::CK);
+            if (t == 0) {
+                if (cc + 2 < nchunk) load_raw((cc + 2) * C::CK);
+                else if (warm) load_raw_next((cc + 2 - nchunk) * C::CK);
+            }
             if (t == 10) store_raw(rnxt);
+            if (t == 11 && warm && cc + 3 == nchunk) halo_offsets(nz0, ny0, nx0);
+            if (t == 11 && warm && cc + 1 == nchunk) load_raw_next(2 * C::CK);     // third image: touched, never stored
             // chunk cc + 1: patch reads one tap ahead of the first piece, two pieces per tap
             if (more && s_on) {
                 if (ROUNDS == 2) {
@@ -328,6 +368,10 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
         }
     }
     SIV_STAMP(29);
+    if (warm) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) asm volatile("" ::"v"(raw[p].x), "v"(raw[p].y), "v"(raw[p].z), "v"(raw[p].w));     // keeps the touching loads alive
+    }
     if (stat_part) {
         // lanes with equal cq (bits 3..5 differ) hold the same four channels
 #pragma unroll
