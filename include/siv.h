@@ -385,6 +385,13 @@ int siv_dropout_keep_at(uint8_t* keep, long n, float p, uint64_t seed, uint64_t 
 /* ---- helpers ------------------------------------------------------------------------ */
 /* y = a*x + b*y elementwise (gradient accumulation on device); x and y must not overlap. */
 int siv_axpby(float a, const float* x, float b, float* y, long n, siv_stream_t stream);
+/* bf16 storage of the tensors the backward pass keeps (no counterpart in the reference, which trains in
+ * fp32 throughout; this is the "bf16 activations" of the 160x192x160 configuration): h[i] = bf16(x[i])
+ * with round-to-nearest-even, and back (exact).  n elements in memory order, both buffers 16-byte
+ * aligned.  Arithmetic stays fp32 everywhere: only what autograd saves between forward and backward is
+ * held at half the size. */
+int siv_f32_to_bf16(const float* x, void* h, long n, siv_stream_t stream);
+int siv_bf16_to_f32(const void* h, float* x, long n, siv_stream_t stream);
 /* x *= a in place: the division by the world size after the gradient all-reduce that replaces
  * nn.DataParallel's reduce_add (main_DataParallel.py:609).  The collective itself is not part of this
  * library: callers run it with torch.distributed (backend "nccl" = RCCL over xGMI) on the same stream. */

@@ -231,6 +231,37 @@ __global__ __launch_bounds__(256) void axpby_k(float a, const float* __restrict_
         y[i] = (b == 0.f) ? a * x[i] : fmaf(a, x[i], b * y[i]);
 }
 
+// ---- bf16 storage of tensors kept for the backward pass ---------------------------------
+// fp32 -> bf16 with round-to-nearest-even (NaN stays NaN), eight elements per thread and step
+// (32 bytes in, 16 bytes out); bf16 -> fp32 is exact.
+__device__ __forceinline__ uint32_t bf16_rne(float f) {
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;        // quiet NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__global__ __launch_bounds__(256) void f32_to_bf16_k(const float* __restrict__ x, uint16_t* __restrict__ h, long n) {
+    const long n8 = n >> 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+        uint4 o;
+        o.x = bf16_rne(a.x) | (bf16_rne(a.y) << 16); o.y = bf16_rne(a.z) | (bf16_rne(a.w) << 16);
+        o.z = bf16_rne(b.x) | (bf16_rne(b.y) << 16); o.w = bf16_rne(b.z) | (bf16_rne(b.w) << 16);
+        reinterpret_cast<uint4*>(h)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) h[(n8 << 3) + threadIdx.x] = (uint16_t)bf16_rne(x[(n8 << 3) + threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_k(const uint16_t* __restrict__ h, float* __restrict__ x, long n) {
+    const long n8 = n >> 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const uint4 v = reinterpret_cast<const uint4*>(h)[i];
+        reinterpret_cast<float4*>(x)[2 * i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                                         __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+        reinterpret_cast<float4*>(x)[2 * i + 1] = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u),
+                                                             __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) x[(n8 << 3) + threadIdx.x] = __uint_as_float((uint32_t)h[(n8 << 3) + threadIdx.x] << 16);
+}
+
 // ---- Philox-4x32-10 (siv_common.h) --------------------------------------------------
 __device__ __forceinline__ float u01(uint32_t r) {  // (0,1]
     return ((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f);
@@ -458,6 +489,20 @@ extern "C" int siv_scale(float a, float* x, long n, siv_stream_t stream) {
     SIV_CHECK_ARG(x && n > 0, "scale: bad argument");
     scale_k<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(a, x, n);
     SIV_CHECK_LAUNCH("scale");
+    return SIV_OK;
+}
+extern "C" int siv_f32_to_bf16(const float* x, void* h, long n, siv_stream_t stream) {
+    SIV_CHECK_ARG(x && h && n > 0, "f32_to_bf16: bad argument");
+    SIV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)h & 15) == 0, "f32_to_bf16: buffers must be 16-byte aligned");
+    f32_to_bf16_k<<<ew_grid(cdiv(n, 8)), 256, 0, (hipStream_t)stream>>>(x, (uint16_t*)h, n);
+    SIV_CHECK_LAUNCH("f32_to_bf16");
+    return SIV_OK;
+}
+extern "C" int siv_bf16_to_f32(const void* h, float* x, long n, siv_stream_t stream) {
+    SIV_CHECK_ARG(x && h && n > 0, "bf16_to_f32: bad argument");
+    SIV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)h & 15) == 0, "bf16_to_f32: buffers must be 16-byte aligned");
+    bf16_to_f32_k<<<ew_grid(cdiv(n, 8)), 256, 0, (hipStream_t)stream>>>((const uint16_t*)h, x, n);
+    SIV_CHECK_LAUNCH("bf16_to_f32");
     return SIV_OK;
 }
 extern "C" int siv_axpby(float a, const float* x, float b, float* y, long n, siv_stream_t stream) {

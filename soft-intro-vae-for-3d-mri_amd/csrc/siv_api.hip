@@ -230,7 +230,7 @@ using namespace siv;
 
 extern "C" const char* siv_last_error(void) { return g_err; }
 extern "C" const char* siv_last_conv_kernel(void) { return g_conv_kernel; }
-extern "C" int siv_version(void) { return 105; }
+extern "C" int siv_version(void) { return 106; }
 extern "C" size_t siv_workspace_bytes(void) { return (size_t)512 << 20; }
 extern "C" int siv_pack_cache_configure(void* mem, size_t bytes) {
     SIV_CHECK_ARG(((uintptr_t)mem & 255) == 0, "pack_cache_configure: memory must be 256-byte aligned");

@@ -73,6 +73,8 @@ SIGNATURES = {
     "siv_dropout_keep": [_f, _l, _fl, _u64, _u64, _f],
     "siv_axpby": [_fl, _f, _fl, _f, _l, _f],
     "siv_scale": [_fl, _f, _l, _f],
+    "siv_f32_to_bf16": [_f, _f, _l, _f],
+    "siv_bf16_to_f32": [_f, _f, _l, _f],
 }
 
 _lib = None

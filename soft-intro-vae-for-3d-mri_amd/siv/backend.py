@@ -709,6 +709,23 @@ class HipBackend:
         assert x.is_contiguous()
         _lib.check(self.lib.siv_scale(float(a), _p(x), x.numel(), self._stream(x)), "siv_scale")
 
+    def to_bf16(self, x):
+        """bf16 copy (round-to-nearest-even) of a dense fp32 tensor, same shape and strides."""
+        self._check_dev(x)
+        h = torch.empty_like(x, dtype=torch.bfloat16)        # preserve_format keeps a dense tensor's strides
+        assert h.stride() == x.stride()
+        _lib.check(self.lib.siv_f32_to_bf16(_p(x), _p(h), x.numel(), self._stream(x)), "siv_f32_to_bf16")
+        return h
+
+    def from_bf16(self, h):
+        """fp32 copy (exact) of a dense bf16 tensor, same shape and strides."""
+        if not h.is_cuda or h.dtype != torch.bfloat16:
+            raise _lib.SivError("from_bf16 needs a bf16 tensor on a HIP device")
+        x = torch.empty_like(h, dtype=torch.float32)
+        assert h.stride() == x.stride()
+        _lib.check(self.lib.siv_bf16_to_f32(_p(h), _p(x), x.numel(), self._stream(x)), "siv_bf16_to_f32")
+        return x
+
     def axpby(self, a: float, x, b: float, y) -> None:
         self._check_dev(x, y)
         assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()

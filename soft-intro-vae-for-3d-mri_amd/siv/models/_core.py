@@ -19,7 +19,7 @@ from dataclasses import dataclass
 import torch
 import torch.nn as nn
 
-from .. import ops, rng
+from .. import activations, ops, rng
 
 
 @dataclass(frozen=True)
@@ -168,6 +168,7 @@ class ResNetEncoder(nn.Module):
             h = blk[0](h)
         return h
 
+    @activations.scoped
     def forward(self, x):
         c = self.conv[0]
         return ops.conv1x1(self.features(x), c.weight, c.bias)
@@ -181,6 +182,7 @@ class VAEResNetEncoder(ResNetEncoder):
         self.mu = nn.Conv3d(self.inner_ch, 1, kernel_size=1, stride=1, bias=True)
         self.var = nn.Conv3d(self.inner_ch, 1, kernel_size=1, stride=1, bias=True)
 
+    @activations.scoped
     def forward(self, x):
         h = self.features(x)
         return ops.conv1x1(h, self.mu.weight, self.mu.bias), ops.conv1x1(h, self.var.weight, self.var.bias)
@@ -216,6 +218,7 @@ class ResNetDecoder(nn.Module):
         blocks.append(nn.Sequential(*tail))
         self.blocks = nn.Sequential(*blocks)
 
+    @activations.scoped
     def forward(self, z):
         v = self.variant
         mods = list(self.blocks)

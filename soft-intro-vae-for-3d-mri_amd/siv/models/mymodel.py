@@ -20,7 +20,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import activations, ops
 from ._core import sample_eps
 
 SLOPE = 0.2          # every nn.LeakyReLU(0.2) of models/mymodel.py
@@ -68,6 +68,7 @@ class ResNetVAEencoder(nn.Module):
         self.Leakyrelu7 = nn.LeakyReLU(SLOPE, inplace=True)
         self.fc = nn.Linear(forth_ch * 5 * 6 * 5, z_ch * 2)
 
+    @activations.scoped
     def forward(self, x):
         t = self.training
         for blk in (self.block1, self.block2, self.block3):         # :128-133, pool fused into the tail
@@ -117,6 +118,7 @@ class ResNetDecoder(nn.Module):
         y = _conv_bn_act(y, blk[0], blk[1], t)
         return _conv_bn_act(y, blk[4], blk[5], t, ups=2)
 
+    @activations.scoped
     def forward(self, z):
         t = self.training
         y = z.reshape(z.size(0), -1)

@@ -199,6 +199,12 @@ class CpuCheckerBackend:
         gen = torch.Generator().manual_seed((seed * 7919 + stream_id) % (2 ** 63))
         return (torch.rand(tuple(shape), generator=gen) >= p).to(torch.uint8)
 
+    def to_bf16(self, x):
+        return x.to(torch.bfloat16)          # torch rounds to nearest even, like siv_f32_to_bf16
+
+    def from_bf16(self, h):
+        return h.to(torch.float32)
+
     def scale_(self, x, a):
         with torch.no_grad():
             x.mul_(a)

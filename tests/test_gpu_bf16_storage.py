@@ -1,0 +1,147 @@
+"""bf16 storage of the tensors kept for the backward pass (siv.activations, siv_f32_to_bf16 /
+siv_bf16_to_f32) on a real MI355X.
+
+The reference trains in fp32 only, so this mode has no reference counterpart: it is checked against
+(a) torch's own fp32 -> bf16 rounding, bit for bit, (b) the fp32 mode of the same model on the same
+device (the forward pass must be bit-identical) and (c) the fp32 CPU oracle.  Tolerance of the
+gradients, stated: 6e-2 of each tensor's maximum against the fp32 oracle.  Every saved activation
+carries a relative rounding error of up to 2^-9 = 2e-3, a pre-activation that close to zero can change
+sides in the LeakyReLU mask the backward pass recomputes, and the E-step gradient is a difference of
+three encoder passes weighted 1 : 1024-scaled exponentials; measured on this model: decoder gradients
+1e-4..3e-2 of max (growing with the distance from the output), encoder gradients 2e-2..4.6e-2, against
+1e-5..2e-2 in the fp32 mode.  That is the price of the mode, not an implementation error: the forward
+pass is bit-identical and the conversions are exact to the last bit."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import siv_oracle as O
+
+pytestmark = pytest.mark.gpu
+WIDE = (64, [[64, 1, 2], [128, 1, 2]])
+BN_CANCELLED = ("encoder.blocks.0.0.bias", "decoder.blocks.0.0.bias", "decoder.blocks.0.0.weight")
+
+
+@pytest.fixture(autouse=True)
+def hip_backend():
+    import siv.activations as act
+    import siv.backend as sb
+    import siv.rng as srng
+    sb.set_backend(None)
+    assert sb.get_backend().name == "hip"
+    yield
+    act.set_storage("fp32")
+    srng.set_rng(srng.DeviceRng(0))
+
+
+@pytest.mark.parametrize("n", [8, 1 << 16, (1 << 20) + 8, (1 << 18) + 5, 7 * 4096 + 3])
+def test_conversion_matches_torch_rounding(n):
+    import siv.backend as sb
+    B = sb.get_backend()
+    gen = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=gen) * torch.exp(8 * torch.randn(n, generator=gen))
+    x[:8] = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1.00390625, 1.01171875, 3.3895314e38])
+    xd = x.cuda()
+    h = B.to_bf16(xd)
+    ref = x.to(torch.bfloat16)
+    a, b = h.cpu().view(torch.int16), ref.view(torch.int16)
+    nan = torch.isnan(ref)
+    assert torch.equal(a[~nan], b[~nan])            # ties to even (1.00390625 -> 1.0, 1.01171875 -> 1.015625), overflow to inf
+    assert torch.isnan(h.cpu()[nan]).all()
+    back = B.from_bf16(h).cpu()
+    assert torch.equal(back[~nan], ref.float()[~nan])
+
+
+def test_conversion_keeps_channels_last_strides():
+    import siv.backend as sb
+    B = sb.get_backend()
+    x = torch.randn(2, 8, 4, 6, 10, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+    h = B.to_bf16(x)
+    assert h.stride() == x.stride() and torch.equal(h, x.to(torch.bfloat16))
+    assert torch.equal(B.from_bf16(h), x.to(torch.bfloat16).float())
+
+
+def _make(seed_w, seed_d, dims, Bn):
+    import siv.models.models as models
+    torch.manual_seed(seed_w)
+    net = models.SoftIntroVAE(*WIDE)
+    gen = torch.Generator().manual_seed(seed_d)
+    with torch.no_grad():
+        for m in net.modules():
+            if type(m) == torch.nn.Conv3d:
+                torch.nn.init.kaiming_normal_(m.weight, nonlinearity="leaky_relu")
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.copy_(1 + 0.2 * torch.randn(m.weight.shape, generator=gen))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+    real = torch.rand(Bn, 1, *dims, generator=gen)
+    noise = torch.randn(Bn, 1, *(d // 4 for d in dims), generator=gen)
+    return net, real, noise
+
+
+def _step(net, real, noise, hp, draws):
+    import siv.rng as srng
+    import siv.utils.my_trainer as trainer
+    from siv.optim import FlatAdam
+    opt_e, opt_d = FlatAdam(net.encoder.parameters(), lr=2e-4), FlatAdam(net.decoder.parameters(), lr=2e-4)
+    step = trainer.SoftIntroStep(net, opt_e, opt_d, hp.beta_rec, hp.beta_neg, hp.beta_kl, hp.gamma_r, hp.scale)
+    grads = {}
+    oe, od = opt_e.step, opt_d.step
+    opt_e.step = lambda: (grads.update({"encoder." + k: p.grad.detach().clone().cpu()
+                                        for k, p in net.encoder.named_parameters()}), oe())
+    opt_d.step = lambda: (grads.update({"decoder." + k: p.grad.detach().clone().cpu()
+                                        for k, p in net.decoder.named_parameters()}), od())
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with srng.use_rng(srng.ReplayRng(draws)):
+        st = dict(zip(trainer.STAT_NAMES, step(real.cuda(), noise.cuda()).cpu().tolist()))
+    return st, grads, torch.cuda.max_memory_allocated() - base
+
+
+def test_bf16_storage_step():
+    """One full E+D iteration of a 64-128 channel model at 32^3, batch 2, with the saved activations held
+    as bf16: forward bit-identical to the fp32 mode, gradients within the stated 6e-2 of the fp32 oracle,
+    less memory at the peak."""
+    import siv.activations as act
+    dims, Bn = (32, 32, 32), 2
+    hp = O.Hyper(dims=dims)
+    net, real, noise = _make(25, 26, dims, Bn)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    ref = O.soft_intro_step(sd, O.Cfg(*WIDE), real, noise, O.Draws(seed=27), hp, {}, {})
+    warm, _, _ = _make(25, 26, dims, Bn)                    # first use allocates workspace and pack cache
+    _step(warm.to("cuda").train(), real, noise, hp, O.Draws(seed=27))
+    del warm
+    net = net.to("cuda").train()
+    st32, g32, peak32 = _step(net, real, noise, hp, O.Draws(seed=27))
+    net2, _, _ = _make(25, 26, dims, Bn)
+    net2 = net2.to("cuda").train()
+    before = dict(act.packed)
+    with act.storage("bf16"):
+        st16, g16, peak16 = _step(net2, real, noise, hp, O.Draws(seed=27))
+    assert act.get_storage() == "fp32"
+    n_packed = act.packed["tensors"] - before["tensors"]
+    assert n_packed >= 40, n_packed                       # 13 encoder/decoder passes x the large saved tensors
+    # everything the E-step reports is forward arithmetic on the initial weights: identical bits
+    for k in ("lossE", "kl_real", "exp_elbo_rec", "exp_elbo_fake"):
+        assert st16[k] == st32[k], (k, st16[k], st32[k])
+    # the D-step runs after an encoder update that used the rounded activations; Adam's first update is
+    # lr * sign(g), so every element whose noise-level gradient changes sign moves the other way: 1e-2
+    for mine, r in (("lossE", "lossE"), ("lossD", "lossD"), ("kl_real", "kl_real"), ("fake_kl", "fake_kl"),
+                    ("rec_kl", "rec_kl"), ("loss_rec", "loss_rec_D")):
+        np.testing.assert_allclose(st16[mine], float(ref[r]), rtol=1e-2, err_msg=mine)
+    worst = worst32 = 0.0
+    for k, gr in g16.items():
+        rg = ref["gradE" if k.startswith("encoder.") else "gradD"][k]
+        if rg is None:
+            assert float(gr.abs().max()) == 0.0, k
+            continue
+        if k.endswith(BN_CANCELLED):
+            continue
+        m = float(rg.abs().max()) + 1e-30
+        err = float((gr - rg).abs().max()) / m
+        assert err <= 6e-2, f"{k}: bf16-storage gradient {err:.2e} of max away from the fp32 oracle"
+        worst, worst32 = max(worst, err), max(worst32, float((g32[k] - rg).abs().max()) / m)
+    assert worst > worst32                                # the mode really was on (and costs accuracy)
+    assert peak16 < 0.8 * peak32, (peak16, peak32)
+    print(f"bf16 storage: {n_packed} tensors packed, worst gradient error {worst:.2e} of max "
+          f"(fp32 mode {worst32:.2e}), peak memory {peak16 / 2**20:.0f} MiB against {peak32 / 2**20:.0f} MiB")

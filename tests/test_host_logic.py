@@ -313,3 +313,46 @@ def test_train_soft_intro_vae_matches_reference_trainer():
             assert int(v) == int(ref_final[k]), k
         else:
             close(v, ref_final[k], rtol=2e-3, atol=2e-3, what="final " + k)
+
+
+def test_bf16_activation_storage_hooks():
+    """siv.activations on the CPU checker: with storage("bf16") the large fp32 tensors saved inside the
+    encoder / decoder passes are held as bf16; parameters, masks and small tensors are not; the forward
+    pass is unchanged and the gradients move by no more than bf16 rounding of the saved tensors explains (5e-2 of max at 8 channels:
+    besides the 2^-9 rounding itself, a pre-activation within 2^-9 of zero can change sides in the recomputed
+    LeakyReLU mask)."""
+    import siv.activations as act
+    cfg = (8, [[8, 1, 2], [16, 1, 2]])
+    dims, bn = (16, 32, 32), 2                     # 8 ch x 16384 voxels x 2: above the size threshold
+    hp = O.Hyper(dims=dims)
+    res = {}
+    for kind in ("fp32", "bf16"):
+        torch.manual_seed(3)
+        net = models.SoftIntroVAE(*cfg)
+        net.apply(trainer.init_weights_he)
+        net.train()
+        gen = torch.Generator().manual_seed(4)
+        real = torch.rand(bn, 1, *dims, generator=gen)
+        noise = torch.randn(*net.latent_shape(bn, dims), generator=gen)
+        oe, od = FlatAdam(net.encoder.parameters(), lr=2e-4), FlatAdam(net.decoder.parameters(), lr=2e-4)
+        step = trainer.SoftIntroStep(net, oe, od, hp.beta_rec, hp.beta_neg, hp.beta_kl, hp.gamma_r, hp.scale)
+        grads = {}
+        e_step = oe.step
+        oe.step = lambda: (grads.update({k: p.grad.detach().clone() for k, p in net.encoder.named_parameters()}),
+                           e_step())
+        before = act.packed["tensors"]
+        with act.storage(kind), srng.use_rng(srng.ReplayRng(O.Draws(seed=5))):
+            st = dict(zip(trainer.STAT_NAMES, step(real, noise).tolist()))
+        res[kind] = (st, grads, act.packed["tensors"] - before)
+    assert res["fp32"][2] == 0 and res["bf16"][2] > 10
+    assert res["bf16"][0]["lossE"] == res["fp32"][0]["lossE"]
+    moved = 0.0
+    for k, g in res["fp32"][1].items():
+        if ("encoder." + k).endswith(BN_CANCELLED):
+            continue
+        err = float((res["bf16"][1][k] - g).abs().max() / (g.abs().max() + 1e-30))
+        assert err <= 5e-2, (k, err)
+        moved = max(moved, err)
+    assert moved > 0.0
+    with pytest.raises(ValueError):
+        act.set_storage("fp16")
