@@ -21,6 +21,9 @@ def main():
     import siv.utils.my_trainer as trainer
     from siv.optim import FlatAdam
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    if len(sys.argv) > 2:                                   # "bf16": saved activations held as bf16
+        import siv.activations as act
+        act.set_storage(sys.argv[2])
     dev = torch.device("cuda")
     torch.manual_seed(82)
     net = models.soft_intro_vae_z1200()
