@@ -221,6 +221,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     // ---- prologue: raw image 0 -> V buffer 0, raw image 1, the first weight fragments
     // (both images are requested before either is waited for)
     load_raw(0);
+    f32x16 acc[4][2];          // [pw][row tile]
     {
         float4 raw1[3];
 #pragma unroll
@@ -228,6 +229,20 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < PD; ++i) bring[i] = buf_load16(wrs, wvo, wso0 + ((i >> 2) * 16 + (i & 3)) * C::SLICE * 4);
         static_assert(12 % PD == 0, "ring index must not depend on the chunk");
+        // the accumulators are cleared here, under the latency of the first loads: 128 vector instructions
+        // per wave that would otherwise sit between the prologue's last barrier and the first matrix instruction
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][a][r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) asm volatile("" : "+v"(acc[p][a]));
+        __builtin_amdgcn_sched_barrier(0);
         store_raw(rimg);
 #pragma unroll
         for (int p = 0; p < 3; ++p) raw[p] = raw1[p];
@@ -245,14 +260,6 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     }
     __syncthreads();
     SIV_STAMP(2);
-
-    f32x16 acc[4][2];          // [pw][row tile]
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[p][a][r] = 0.f;
 
     for (int cc = 0; cc < nchunk; ++cc) {
         const float* cur = lds + (cc & 1) * C::V_FLOATS;
