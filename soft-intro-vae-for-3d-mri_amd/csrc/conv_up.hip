@@ -337,12 +337,17 @@ __global__ __launch_bounds__(256, 2) void k2_up_fwd_prod(const float* __restrict
     if (m >= C::M) m = 0;
     const int aoff = (((m / (LBH * LBW)) * C::HH + (m / LBW) % LBH) * C::HW + m % LBW) * C::CKP + 4 * lh;
     constexpr int NTAP = 18, PD = 3;
-    const float* wlane = wp + ((long)(blockIdx.y * 2 + ad) * nchunk) * NTAP * C::SLICE + (wn * 32 + li) * 8 + 4 * lh;
+    // Weights and halo go through buffer descriptors: per-lane offsets stay constant, everything that moves
+    // is scalar, and a halo voxel outside the volume (offset beyond the descriptor) reads zeros -- no 64-bit
+    // address arithmetic and no masking on the vector ALU, whose instructions take matrix-pipe time here.
+    const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(wp, (long)gridDim.y * 2 * nchunk * NTAP * C::SLICE * 4);
+    const unsigned wvo = ((wn * 32 + li) * 8 + 4 * lh) * 4;
+    const int wso0 = (int)(blockIdx.y * 2 + ad) * nchunk * NTAP * C::SLICE * 4;
     float4 bring[PD];
 
+    const __amdgpu_buffer_rsrc_t xrs = buf_rsrc(x + (long)n * Dl * Hl * Wl * Cin, (long)Dl * Hl * Wl * Cin * 4);
     float4 hreg[C::NH];
-    long hoff[C::NH];
-    unsigned hmask = 0;
+    unsigned hoff[C::NH];
 #pragma unroll
     for (int i = 0; i < C::NH; ++i) {
         const int idx = tid + C::NTHR * i;
@@ -350,16 +355,15 @@ __global__ __launch_bounds__(256, 2) void k2_up_fwd_prod(const float* __restrict
         const int hx = hv % C::HW, hy = (hv / C::HW) % C::HH, hz = hv / (C::HW * C::HH);
         const int gz = z0 + ad - 1 + hz, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
         const bool ok = hv < C::HV && gz >= 0 && gz < Dl && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl;
-        hoff[i] = ok ? ((((long)n * Dl + gz) * Hl + gy) * Wl + gx) * Cin + 4 * q : 0;
-        hmask |= (unsigned)ok << i;
+        hoff[i] = ok ? (unsigned)((((gz * Hl + gy) * Wl + gx) * Cin + 4 * q) * 4) : 0x80000000u;
     }
     auto load_halo = [&](int c0) {
 #pragma unroll
-        for (int i = 0; i < C::NH; ++i) hreg[i] = *reinterpret_cast<const float4*>(x + hoff[i] + c0);
+        for (int i = 0; i < C::NH; ++i) hreg[i] = buf_load16(xrs, hoff[i], c0 * 4);
     };
     load_halo(0);
 #pragma unroll
-    for (int i = 0; i < PD; ++i) bring[i] = *reinterpret_cast<const float4*>(wlane + i * C::SLICE);
+    for (int i = 0; i < PD; ++i) bring[i] = buf_load16(wrs, wvo, wso0 + i * C::SLICE * 4);
 #define SIV_PIN(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
 #pragma unroll
     for (int i = 0; i < C::NH; ++i) SIV_PIN(hreg[i]);
@@ -367,29 +371,39 @@ __global__ __launch_bounds__(256, 2) void k2_up_fwd_prod(const float* __restrict
     for (int i = 0; i < PD; ++i) SIV_PIN(bring[i]);
 #undef SIV_PIN
 
-    auto sub4 = [](float4 a, float4 c) { return make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w); };
+    // four-channel differences as two packed two-channel subtractions (vector instructions take matrix-pipe
+    // time on a SIMD that runs fp32 matrix instructions, so their count matters)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    struct f32x4 { f32x2 lo, hi; };
+    // (spelled as the instruction: the compiler splits a packed subtraction whose halves feed different
+    // matrix instructions into two scalar ones)
+    auto pk_sub = [](f32x2 a, f32x2 c) {
+        f32x2 r;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(c));
+        return r;
+    };
+    auto sub4 = [&](f32x4 a, f32x4 c) { return f32x4{pk_sub(a.lo, c.lo), pk_sub(a.hi, c.hi)}; };
     for (int cc = 0; cc < nchunk; ++cc) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < C::NH; ++i) {
             const int idx = tid + C::NTHR * i;
-            if (!((hmask >> i) & 1)) hreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((idx >> 1) < C::HV)
                 *reinterpret_cast<float4*>(lds + (idx >> 1) * C::CKP + 4 * (idx & 1)) = hreg[i];
         }
         __syncthreads();
         load_halo((cc + 1 < nchunk ? cc + 1 : cc) * C::CK);
-        const float* wc = wlane + (long)cc * NTAP * C::SLICE;
+        const int wso = wso0 + cc * NTAP * C::SLICE * 4;
 #pragma unroll
         for (int sd = 0; sd < 2; ++sd) {
             // 3x3 neighbourhood of the row's voxel in plane sd, differences along W, then along H
-            float4 d[3][3];
+            f32x4 d[3][3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const float* row = lds + aoff + ((sd * C::HH + r) * C::HW) * C::CKP;
-                const float4 c0 = *reinterpret_cast<const float4*>(row);
-                const float4 c1 = *reinterpret_cast<const float4*>(row + C::CKP);
-                const float4 c2 = *reinterpret_cast<const float4*>(row + 2 * C::CKP);
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(row);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(row + C::CKP);
+                const f32x4 c2 = *reinterpret_cast<const f32x4*>(row + 2 * C::CKP);
                 d[r][0] = sub4(c0, c1);
                 d[r][1] = c1;
                 d[r][2] = sub4(c2, c1);
@@ -397,14 +411,14 @@ __global__ __launch_bounds__(256, 2) void k2_up_fwd_prod(const float* __restrict
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int ph = t / 3, pw = t % 3, tt = sd * 9 + t;
-                const float4 av = ph == 0 ? sub4(d[0][pw], d[1][pw]) : ph == 1 ? d[1][pw] : sub4(d[2][pw], d[1][pw]);
+                const f32x4 av = ph == 0 ? sub4(d[0][pw], d[1][pw]) : ph == 1 ? d[1][pw] : sub4(d[2][pw], d[1][pw]);
                 const float4 bv = bring[tt % PD];
-                bring[tt % PD] = *reinterpret_cast<const float4*>(wc + (tt + PD) * C::SLICE);
+                bring[tt % PD] = buf_load16(wrs, wvo, wso + (tt + PD) * C::SLICE * 4);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.lo.x, bv.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.lo.y, bv.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.hi.x, bv.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.hi.y, bv.w, acc[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -655,6 +669,8 @@ template <int LBD, int LBH, int LBW>
 static int up_launch_prod(const float* x, const void* wp, const float* bias, float* y, int N, int D, int H,
                           int W, int Cin, int Cout, hipStream_t s, float* stat_part) {
     using C = UpCfg<LBD, LBH, LBW>;
+    SIV_CHECK_ARG((long)(D / 2) * (H / 2) * (W / 2) * Cin < (1L << 29),
+                  "conv3d_k3(upsampled, product form): sample too large for 32-bit byte offsets");
     const int nbd = (int)cdiv(D / 2, LBD), nbh = (int)cdiv(H / 2, LBH), nbw = (int)cdiv(W / 2, LBW);
     const long nblk = (long)N * nbd * nbh * nbw * 2;
     if (nblk > 0x7fffffffL) {
