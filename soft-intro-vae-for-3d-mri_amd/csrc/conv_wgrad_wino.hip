@@ -50,16 +50,20 @@ struct GwGeom {
 };
 
 // The work of one wave over all items of its block.  ISV: the wave stages x (4x4 patch, two rows of it
-// for position row ph), else dy (2x2 tile).  `src` points at the lane's four channels of voxel 0, `Cs`
-// is the channel count of that tensor.  The row combination is written with coefficients instead of
-// cases, so that the multiply loop is one basic block per role:
-//   x:  h = a + sB b         (sB = +1 for ph = 1, else -1; rows (A, B) = (0,2) (1,2) (2,1) (3,1))
-//   dy: h = a/2 + sB b       (sB = -1/2 for ph = 2, else 1/2; rows (0,0) (0,1) (0,1) (1,1))
-// with the coefficients of voxels outside the volume set to zero (their loads read voxel 0).
+// for position row ph), else dy (2x2 tile).  `src` is the tensor, `chan` the first of the lane's four
+// channels, `Cs` the channel count of that tensor.  The row combination is h = a + cB b with
+//   x:  cB = +1 for ph = 1, else -1; rows (A, B) = (0,2) (1,2) (2,1) (3,1)
+//   dy: cB = 0, +1, -1, 0;           rows (A, B) = (0,0) (0,1) (0,1) (1,1)
+// The factors 1/2 of G (positions 1 and 2 along either axis) are left out of the dy transform and applied
+// to the finished sums (exact: powers of two).  A sample is read through a buffer descriptor whose per-lane
+// offset carries voxel AND plane, so a voxel or a whole plane outside the volume reads zeros: no masks, no
+// 64-bit address arithmetic, and the transforms are packed two-channel operations -- every vector
+// instruction a wave issues here takes time on the matrix pipe.
 template <bool ISV>
-__device__ __forceinline__ void gw_run(const float* __restrict__ src, const int Cs, f32x16 (&acc)[3][2],
-                                       float* lds, const int ph, const int set, const GwGeom g,
-                                       const int aoff, const int boff, const int cg, const int tile) {
+__device__ __forceinline__ void gw_run(const float* __restrict__ src, const int chan, const int Cs,
+                                       f32x16 (&acc)[3][2], float* lds, const int ph, const int set,
+                                       const GwGeom g, const int aoff, const int boff, const int cg,
+                                       const int tile) {
     using C = GwCfg;
     constexpr int NC = ISV ? 4 : 2;
     const int th = tile / g.tpr, tw = tile - th * g.tpr;
@@ -68,46 +72,52 @@ __device__ __forceinline__ void gw_run(const float* __restrict__ src, const int 
     const int soff = (4 * cg) * C::CS + tile;                          // + position * 64 * CS + e * CS
     const int rA = ISV ? ph : (ph == 3 ? 1 : 0);
     const int rB = ISV ? (ph <= 1 ? 2 : 1) : (ph == 0 ? 0 : 1);
-    const float kA = ISV ? 1.f : 0.5f;
-    const float kB = ISV ? (ph == 1 ? 1.f : -1.f) : (ph == 2 ? -0.5f : 0.5f);
-    const long plane = (long)g.H * g.W * Cs;
+    const float kB = ISV ? (ph == 1 ? 1.f : -1.f) : (ph == 1 ? 1.f : ph == 2 ? -1.f : 0.f);
+    const f32x2_t kB2 = {kB, kB};
+    const unsigned plane4 = (unsigned)(g.H * g.W * Cs) * 4u;              // bytes of a plane
+    constexpr unsigned OUTSIDE = 0x80000000u;
 
-    f32x4 pa[NC], pb[NC];
-    int oa[NC], ob[NC];
-    float ca[NC], cb[NC];
-    const float* sn = src;
+    f32x2x2 pa[NC], pb[NC];
+    unsigned oa[NC], ob[NC];
+    __amdgpu_buffer_rsrc_t rs = buf_rsrc(src, 0);
 
+    // plane z of this item's sample; z may lie outside [0, D): the offset is then outside the descriptor
     auto issue_col = [&](int c, int z) {
         if (SIV_GWEXP & 1) return;
-        z = z < 0 ? 0 : z >= g.D ? g.D - 1 : z;
-        const float* pl = sn + (long)z * plane;
-        pa[c] = *reinterpret_cast<const f32x4*>(pl + oa[c]);
-        pb[c] = *reinterpret_cast<const f32x4*>(pl + ob[c]);
+        const unsigned zo = (unsigned)z * plane4;
+        pa[c] = buf_load16p(rs, oa[c] + zo, 0);
+        pb[c] = buf_load16p(rs, ob[c] + zo, 0);
     };
-    // rows A and B of column c combined in place (zs = 0 for a plane outside the volume)
-    auto hxf_col = [&](int c, float zs) {
-        const float fa = ca[c] * zs, fb = cb[c] * zs;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pa[c][e] = __builtin_fmaf(fb, pb[c][e], fa * pa[c][e]);
+    // rows A and B of column c combined in place
+    auto hxf_col = [&](int c) {
+        pa[c].lo = pk_fma(kB2, pb[c].lo, pa[c].lo);
+        pa[c].hi = pk_fma(kB2, pb[c].hi, pa[c].hi);
     };
     // transform along W for position (ph, p), then its four channel rows
     auto wpiece = [&](int p, float* dst) {
-        f32x4 v;
-        if (ISV) v = p == 0 ? pa[0] - pa[NC - 2] : p == 1 ? pa[1] + pa[NC - 2] : p == 2 ? pa[NC - 2] - pa[1] : pa[NC - 1] - pa[1];
-        else v = p == 0 ? pa[0] : p == 1 ? 0.5f * pa[0] + 0.5f * pa[1] : p == 2 ? 0.5f * pa[0] - 0.5f * pa[1] : pa[1];
+        f32x2x2 v;
+        if (ISV) {
+            if (p == 0) v = {pk_sub(pa[0].lo, pa[NC - 2].lo), pk_sub(pa[0].hi, pa[NC - 2].hi)};
+            else if (p == 1) v = {pk_add(pa[1].lo, pa[NC - 2].lo), pk_add(pa[1].hi, pa[NC - 2].hi)};
+            else if (p == 2) v = {pk_sub(pa[NC - 2].lo, pa[1].lo), pk_sub(pa[NC - 2].hi, pa[1].hi)};
+            else v = {pk_sub(pa[NC - 1].lo, pa[1].lo), pk_sub(pa[NC - 1].hi, pa[1].hi)};
+        } else {
+            if (p == 0) v = pa[0];
+            else if (p == 1) v = {pk_add(pa[0].lo, pa[1].lo), pk_add(pa[0].hi, pa[1].hi)};
+            else if (p == 2) v = {pk_sub(pa[0].lo, pa[1].lo), pk_sub(pa[0].hi, pa[1].hi)};
+            else v = pa[1];
+        }
         float* d = dst + p * 64 * C::CS + soff;
-        d[0] = v[0]; d[C::CS] = v[1]; d[2 * C::CS] = v[2]; d[3 * C::CS] = v[3];
+        d[0] = v.lo.x; d[C::CS] = v.lo.y; d[2 * C::CS] = v.hi.x; d[3 * C::CS] = v.hi.y;
     };
     auto vbuf = [&](int z) { return lds + (C::NU + (z & 1)) * C::BUF; };
     auto ubuf = [&](int z) { return lds + (z & 3) * C::BUF; };
-    auto zscale = [&](int z) { return (z >= 0 && z < g.D) ? 1.f : 0.f; };
     // immediate staging of one plane (pipeline fill)
     auto stage_now = [&](int z) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) issue_col(c, z);
-        const float zs = zscale(z);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) hxf_col(c, zs);
+        for (int c = 0; c < NC; ++c) hxf_col(c);
         float* dst = ISV ? vbuf(z) : ubuf(z);
 #pragma unroll
         for (int p = 0; p < 4; ++p) wpiece(p, dst);
@@ -123,18 +133,16 @@ __device__ __forceinline__ void gw_run(const float* __restrict__ src, const int 
         const int zlo = (int)((long)zp * g.D / g.zsplit), zhi = (int)((long)(zp + 1) * g.D / g.zsplit);
         if (zlo >= zhi) continue;
 
-        // offsets and coefficients of this item's 2 x NC voxels
+        // byte offsets of this item's 2 x NC voxels inside a plane of its sample
         const int gy0 = ry * colh + 2 * th + (ISV ? -1 : 0), gx0 = rx * colw + 2 * tw + (ISV ? -1 : 0);
         const bool okA = tile_ok && gy0 + rA >= 0 && gy0 + rA < g.H, okB = tile_ok && gy0 + rB >= 0 && gy0 + rB < g.H;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const bool okx = gx0 + c >= 0 && gx0 + c < g.W;
-            oa[c] = (okx && okA) ? ((gy0 + rA) * g.W + gx0 + c) * Cs : 0;
-            ob[c] = (okx && okB) ? ((gy0 + rB) * g.W + gx0 + c) * Cs : 0;
-            ca[c] = (okx && okA) ? kA : 0.f;
-            cb[c] = (okx && okB) ? kB : 0.f;
+            oa[c] = (okx && okA) ? (unsigned)((((gy0 + rA) * g.W + gx0 + c) * Cs + chan) * 4) : OUTSIDE;
+            ob[c] = (okx && okB) ? (unsigned)((((gy0 + rB) * g.W + gx0 + c) * Cs + chan) * 4) : OUTSIDE;
         }
-        sn = src + (long)n * g.D * plane;
+        rs = buf_rsrc(src + (long)n * g.D * g.H * g.W * Cs, (long)g.D * plane4);
 
         // fill: V[zlo], U[zlo-1], U[zlo], U[zlo+1]; then the loads of the first step's staging
         if (ISV) {
@@ -155,7 +163,6 @@ __device__ __forceinline__ void gw_run(const float* __restrict__ src, const int 
             // fetches the planes after them; past the end of the item both are harmless extra work
             const int zst = ISV ? z + 1 : z + 2;
             float* dst = ISV ? vbuf(zst) : ubuf(zst);
-            const float zs = zscale(zst);
             f32x4 af[2][2], bf[2][3];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -182,7 +189,7 @@ __device__ __forceinline__ void gw_run(const float* __restrict__ src, const int 
                     acc[k][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][a][e], bf[j][k][e], acc[k][a], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(SIV_GWEXP & 2)) {
-                    if (m >= 2 && m < 2 + NC) hxf_col(m - 2, zs);
+                    if (m >= 2 && m < 2 + NC) hxf_col(m - 2);
                     if (m == 8 || m == 11 || m == 14 || m == 17) wpiece((m - 8) / 3, dst);
                 }
                 // The loads of the next planes go last, into the registers the transform has just
@@ -231,8 +238,8 @@ __global__ __launch_bounds__(512, 2) void k3_wgrad_wino2d(const float* __restric
     const int st = tid & 255;
     const int cg = st & 15, tile = st >> 4;
     const GwGeom g = {N, D, H, W, nrh, nrw, zsplit, nsets, tpr};
-    if (wave < 4) gw_run<true>(x + cit * 64 + 4 * cg, Cin, acc, lds, ph, set, g, aoff, boff, cg, tile);
-    else gw_run<false>(dy + cot * 64 + 4 * cg, Cout, acc, lds, ph, set, g, aoff, boff, cg, tile);
+    if (wave < 4) gw_run<true>(x, cit * 64 + 4 * cg, Cin, acc, lds, ph, set, g, aoff, boff, cg, tile);
+    else gw_run<false>(dy, cot * 64 + 4 * cg, Cout, acc, lds, ph, set, g, aoff, boff, cg, tile);
 
     // partial sums of this block
     float* pp = part + ((((long)set * gridDim.y + blockIdx.y) * 4 + ph) * 4 + pw) * 3 * 4096;
@@ -270,8 +277,12 @@ __global__ __launch_bounds__(256) void k3_wgrad_wino2d_finish(const float* __res
         for (int p = 0; p < 16; ++p) m[p] = 0.f;
         {   // the sets have been summed into part[0] (gw_sum_sets)
             const float* pp = part + ((long)tl * 16) * 3 * 4096 + (kd * 64 + ci) * 64 + co;
+            // (the factors 1/2 of the dy transform, positions 1 and 2 along H and along W, are applied here)
 #pragma unroll
-            for (int p = 0; p < 16; ++p) m[p] = pp[(long)p * 3 * 4096];
+            for (int p = 0; p < 16; ++p) {
+                const float sc = (((p >> 2) == 1 || (p >> 2) == 2) ? 0.5f : 1.f) * (((p & 3) == 1 || (p & 3) == 2) ? 0.5f : 1.f);
+                m[p] = sc * pp[(long)p * 3 * 4096];
+            }
         }
         // rows of A^T over ph, then over pw
         float t[3][4];
@@ -320,52 +331,57 @@ struct GuCfg {
 };
 
 // ISV: the wave stages x (low resolution; NP = 1 plane per step), else dy (NP = 2 planes per step).
-// D, H, W in `g` are the full-resolution extents.
+// D, H, W in `g` are the full-resolution extents.  Loads, row combination h = a + cB b and the deferred
+// factors 1/2 of the dy transform (position 1 along either axis) as in gw_run.
 template <bool ISV>
-__device__ __forceinline__ void gu_run(const float* __restrict__ src, const int Cs, f32x16 (&acc)[3][2],
-                                       float* lds, const int phi, const int set, const GwGeom g,
-                                       const int aoff, const int boff, const int zt, const int cg,
-                                       const int tile) {
+__device__ __forceinline__ void gu_run(const float* __restrict__ src, const int chan, const int Cs,
+                                       f32x16 (&acc)[3][2], float* lds, const int phi, const int set,
+                                       const GwGeom g, const int aoff, const int boff, const int zt,
+                                       const int cg, const int tile) {
     using C = GuCfg;
     constexpr int NC = ISV ? 3 : 2, NP = ISV ? 1 : 2;
     const int th = tile >> 2, tw = tile & 3;
     const int soff = (4 * cg) * C::CS + tile;
     const int Dl = g.D >> 1, Hs = ISV ? g.H >> 1 : g.H, Ws = ISV ? g.W >> 1 : g.W, Ds = ISV ? Dl : g.D;
     // rows combined for position row phi (positions 0, 1, 3):
-    //   x:  (jy-1, jy; 1, -1)  (jy, jy; 1, 1)  (jy+1, jy; 1, -1)      dy: (0, 0) (0, 1) (1, 1), halves
+    //   x:  (jy-1, jy; -1)  (jy, jy; +1)  (jy+1, jy; -1)      dy: (0, 0; 0) (0, 1; +1) (1, 1; 0)
     const int rA = ISV ? phi - 1 : (phi == 2 ? 1 : 0);
     const int rB = ISV ? 0 : (phi == 0 ? 0 : 1);
-    const float kA = ISV ? 1.f : 0.5f;
-    const float kB = ISV ? (phi == 1 ? 1.f : -1.f) : 0.5f;
-    const long plane = (long)Hs * Ws * Cs;
+    const float kB = ISV ? (phi == 1 ? 1.f : -1.f) : (phi == 1 ? 1.f : 0.f);
+    const f32x2_t kB2 = {kB, kB};
+    const unsigned plane4 = (unsigned)(Hs * Ws * Cs) * 4u;
+    constexpr unsigned OUTSIDE = 0x80000000u;
 
-    f32x4 pa[NP][NC], pb[NP][NC];
-    int oa[NC], ob[NC];
-    float ca[NC], cb[NC];
-    const float* sn = src;
+    f32x2x2 pa[NP][NC], pb[NP][NC];
+    unsigned oa[NC], ob[NC];
+    __amdgpu_buffer_rsrc_t rs = buf_rsrc(src, 0);
 
     auto issue_col = [&](int q, int c, int z) {
-        z = z < 0 ? 0 : z >= Ds ? Ds - 1 : z;
-        const float* pl = sn + (long)z * plane;
-        pa[q][c] = *reinterpret_cast<const f32x4*>(pl + oa[c]);
-        pb[q][c] = *reinterpret_cast<const f32x4*>(pl + ob[c]);
+        const unsigned zo = (unsigned)z * plane4;
+        pa[q][c] = buf_load16p(rs, oa[c] + zo, 0);
+        pb[q][c] = buf_load16p(rs, ob[c] + zo, 0);
     };
-    auto hxf_col = [&](int q, int c, float zs) {
-        const float fa = ca[c] * zs, fb = cb[c] * zs;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) pa[q][c][e] = __builtin_fmaf(fb, pb[q][c][e], fa * pa[q][c][e]);
+    auto hxf_col = [&](int q, int c) {
+        pa[q][c].lo = pk_fma(kB2, pb[q][c].lo, pa[q][c].lo);
+        pa[q][c].hi = pk_fma(kB2, pb[q][c].hi, pa[q][c].hi);
     };
     // position (phi, p), p = 0, 1, 2 standing for 0, 1, 3
     auto wpiece = [&](int q, int p, float* dst) {
-        f32x4 v;
-        if (ISV) v = p == 0 ? pa[q][0] - pa[q][1] : p == 1 ? pa[q][1] + pa[q][1] : pa[q][NC - 1] - pa[q][1];
-        else v = p == 0 ? pa[q][0] : p == 1 ? 0.5f * pa[q][0] + 0.5f * pa[q][1] : pa[q][1];
+        f32x2x2 v;
+        if (ISV) {
+            if (p == 0) v = {pk_sub(pa[q][0].lo, pa[q][1].lo), pk_sub(pa[q][0].hi, pa[q][1].hi)};
+            else if (p == 1) v = {pk_add(pa[q][1].lo, pa[q][1].lo), pk_add(pa[q][1].hi, pa[q][1].hi)};
+            else v = {pk_sub(pa[q][NC - 1].lo, pa[q][1].lo), pk_sub(pa[q][NC - 1].hi, pa[q][1].hi)};
+        } else {
+            if (p == 0) v = pa[q][0];
+            else if (p == 1) v = {pk_add(pa[q][0].lo, pa[q][1].lo), pk_add(pa[q][0].hi, pa[q][1].hi)};
+            else v = pa[q][1];
+        }
         float* d = dst + p * 64 * C::CS + soff;
-        d[0] = v[0]; d[C::CS] = v[1]; d[2 * C::CS] = v[2]; d[3 * C::CS] = v[3];
+        d[0] = v.lo.x; d[C::CS] = v.lo.y; d[2 * C::CS] = v.hi.x; d[3 * C::CS] = v.hi.y;
     };
     auto vbuf = [&](int z) { return lds + (C::NU + (z & 1)) * C::BUF; };
     auto ubuf = [&](int z) { return lds + ((z + 6) % 6) * C::BUF; };        // z >= -1
-    auto zscale = [&](int z) { return (z >= 0 && z < Ds) ? 1.f : 0.f; };
     auto stage_now = [&](int z) {                      // planes z .. z + NP - 1
 #pragma unroll
         for (int q = 0; q < NP; ++q)
@@ -373,9 +389,8 @@ __device__ __forceinline__ void gu_run(const float* __restrict__ src, const int 
             for (int c = 0; c < NC; ++c) issue_col(q, c, z + q);
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            const float zs = zscale(z + q);
 #pragma unroll
-            for (int c = 0; c < NC; ++c) hxf_col(q, c, zs);
+            for (int c = 0; c < NC; ++c) hxf_col(q, c);
             float* dst = ISV ? vbuf(z + q) : ubuf(z + q);
 #pragma unroll
             for (int p = 0; p < 3; ++p) wpiece(q, p, dst);
@@ -398,12 +413,10 @@ __device__ __forceinline__ void gu_run(const float* __restrict__ src, const int 
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const bool okx = gx0 + c >= 0 && gx0 + c < Ws;
-            oa[c] = (okx && okA) ? ((gy0 + rA) * Ws + gx0 + c) * Cs : 0;
-            ob[c] = (okx && okB) ? ((gy0 + rB) * Ws + gx0 + c) * Cs : 0;
-            ca[c] = (okx && okA) ? kA : 0.f;
-            cb[c] = (okx && okB) ? kB : 0.f;
+            oa[c] = (okx && okA) ? (unsigned)((((gy0 + rA) * Ws + gx0 + c) * Cs + chan) * 4) : OUTSIDE;
+            ob[c] = (okx && okB) ? (unsigned)((((gy0 + rB) * Ws + gx0 + c) * Cs + chan) * 4) : OUTSIDE;
         }
-        sn = src + (long)n * Ds * plane;
+        rs = buf_rsrc(src + (long)n * Ds * Hs * Ws * Cs, (long)Ds * plane4);
 
         // fill: V[slo], U[2 slo - 1 .. 2 slo + 2]; then the loads of the first step's staging
         if (ISV) {
@@ -426,7 +439,6 @@ __device__ __forceinline__ void gu_run(const float* __restrict__ src, const int 
             const int zst = ISV ? z + 1 : 2 * z + 3;
             float* dst0 = ISV ? vbuf(zst) : ubuf(zst);
             float* dst1 = ISV ? dst0 : ubuf(zst + 1);
-            const float zs0 = zscale(zst), zs1 = zscale(zst + 1);
             f32x4 af[2][3][2], bf[2][3];
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -447,11 +459,11 @@ __device__ __forceinline__ void gu_run(const float* __restrict__ src, const int 
                     acc[p][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][p][a][e], bf[j][p][e], acc[p][a], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (ISV) {
-                    if (m >= 2 && m < 5) hxf_col(0, m - 2, zs0);
+                    if (m >= 2 && m < 5) hxf_col(0, m - 2);
                     if (m == 8 || m == 11 || m == 14) wpiece(0, (m - 8) / 3, dst0);
                     if (m >= 20 && m < 23) issue_col(0, m - 20, zst + 1);
                 } else {
-                    if (m >= 2 && m < 6) hxf_col((m - 2) >> 1, (m - 2) & 1, (m - 2) >> 1 ? zs1 : zs0);
+                    if (m >= 2 && m < 6) hxf_col((m - 2) >> 1, (m - 2) & 1);
                     if (m >= 7 && m < 19 && ((m - 7) & 1) == 0) wpiece((m - 7) / 6, ((m - 7) >> 1) % 3, (m - 7) / 6 ? dst1 : dst0);
                     if (m >= 20) issue_col((m - 20) >> 1, (m - 20) & 1, zst + 2 + ((m - 20) >> 1));
                 }
@@ -490,8 +502,8 @@ __global__ __launch_bounds__(512, 2) void k2_up_wgrad_wino(const float* __restri
     const int st = tid & 255;
     const int cg = st & 15, tile = st >> 4;
     const GwGeom g = {N, D, H, W, nrh, nrw, zsplit, nsets, 4};
-    if (wave < 4) gu_run<true>(x + cit * 64 + 4 * cg, Cin, acc, lds, phi, set, g, aoff, boff, zt, cg, tile);
-    else gu_run<false>(dy + cot * 64 + 4 * cg, Cout, acc, lds, phi, set, g, aoff, boff, zt, cg, tile);
+    if (wave < 4) gu_run<true>(x, cit * 64 + 4 * cg, Cin, acc, lds, phi, set, g, aoff, boff, zt, cg, tile);
+    else gu_run<false>(dy, cot * 64 + 4 * cg, Cout, acc, lds, phi, set, g, aoff, boff, zt, cg, tile);
 
     float* pp = part + (((long)set * gridDim.y + blockIdx.y) * 3 + phi) * 12 * 4096;
 #pragma unroll
@@ -517,8 +529,10 @@ __global__ __launch_bounds__(256) void k2_up_wgrad_wino_finish(const float* __re
         for (int q = 0; q < 36; ++q) m[q] = 0.f;
         {   // the sets have been summed into part[0] (gw_sum_sets)
             const float* pp = part + (long)tl * 36 * 4096 + ci * 64 + co;
+            // (the factors 1/2 of the dy transform, position 1 along H and along W, are applied here)
 #pragma unroll
-            for (int q = 0; q < 36; ++q) m[q] = pp[(long)q * 4096];
+            for (int q = 0; q < 36; ++q)
+                m[q] = ((q / 12 == 1) ? 0.5f : 1.f) * (((q / 4) % 3 == 1) ? 0.5f : 1.f) * pp[(long)q * 4096];
         }
         const int cog = (tl % ncot) * 64 + co, cig = (tl / ncot) * 64 + ci;
 #pragma unroll
@@ -559,8 +573,8 @@ size_t k2_up_wgrad_wino_ws_bytes(int Cin, int Cout) {
 int k2_up_wgrad_wino_launch(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Cin,
                             int Cout, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
     SIV_CHECK_WS(k2_up_wgrad_wino_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3_wgrad(upsampled, winograd)");
-    SIV_CHECK_ARG((long)H * W * (Cin > Cout ? Cin : Cout) < (1L << 29),
-                  "conv3d_k3_wgrad(upsampled, winograd): plane too large for 32-bit offsets");
+    SIV_CHECK_ARG((long)(D + 3) * H * W * (Cin > Cout ? Cin : Cout) < (1L << 29),
+                  "conv3d_k3_wgrad(upsampled, winograd): sample too large for 32-bit byte offsets");
     const int ntile = (Cin / 64) * (Cout / 64);
     const int nsets = gu_nsets(Cin, Cout);
     const int nrh = (H + 7) / 8, nrw = (W + 7) / 8;
@@ -604,8 +618,8 @@ size_t k3_wgrad_wino2d_ws_bytes(int Cin, int Cout) {
 int k3_wgrad_wino2d_launch(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Cin,
                            int Cout, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
     SIV_CHECK_WS(k3_wgrad_wino2d_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3_wgrad(winograd)");
-    SIV_CHECK_ARG((long)H * W * (Cin > Cout ? Cin : Cout) < (1L << 29),
-                  "conv3d_k3_wgrad(winograd): plane too large for 32-bit offsets");
+    SIV_CHECK_ARG((long)(D + 3) * H * W * (Cin > Cout ? Cin : Cout) < (1L << 29),
+                  "conv3d_k3_wgrad(winograd): sample too large for 32-bit byte offsets");
     const int ntile = (Cin / 64) * (Cout / 64);
     const int nsets = gw_nsets(Cin, Cout);
     // 6 x 10-voxel columns (15 tiles) where they cover the plane with less padding than 8 x 8 ones

@@ -204,7 +204,7 @@ static bool use_w2d(int path, bool aligned, int ups, int N, int D, int H, int W,
 // for its 256 persistent blocks, planes that fill at least 45 % of their columns
 static bool use_gw(int path, bool aligned, int ups, int N, int D, int H, int W, int Cin, int Cout) {
     if (!aligned || !k3_wgrad_wino2d_supported(Cin, Cout)) return false;
-    if ((long)H * W * (Cin > Cout ? Cin : Cout) >= (1L << 29)) return false;
+    if ((long)(D + 3) * H * W * (Cin > Cout ? Cin : Cout) >= (1L << 29)) return false;   // 32-bit byte offsets inside a sample
     if (path == 6) return true;
     if (path != 0 && path != 5) return false;
     // columns of 8 x 8 voxels, or (non-upsampled kernel) of 6 x 10 where those pad less

@@ -55,6 +55,30 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* base, long bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
+// Packed two-element fp32 arithmetic, spelled as the instructions: on a SIMD that runs fp32 matrix
+// instructions every vector instruction takes matrix-pipe time, and the compiler splits a packed operation
+// whose halves are consumed separately into two scalar ones.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t pk_add(f32x2_t a, f32x2_t b) {
+    f32x2_t r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2_t pk_sub(f32x2_t a, f32x2_t b) {
+    f32x2_t r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) {      // a * b + c
+    f32x2_t r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+struct f32x2x2 { f32x2_t lo, hi; };                       // four channels as two register pairs
+__device__ __forceinline__ f32x2x2 buf_load16p(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    const f32x4_t f = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    return f32x2x2{f32x2_t{f.x, f.y}, f32x2_t{f.z, f.w}};
+}
 __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
     const f32x4_t f = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
     return make_float4(f.x, f.y, f.z, f.w);
