@@ -65,9 +65,8 @@ struct W2Cfg {
     static constexpr int EPI_STRIDE = 36, EPI_TILE = 32 * EPI_STRIDE;
     static constexpr int RAW_ITEMS = 3 * NTHR;             // 16-byte items of a raw halo image (1536 >= 2 * 600)
     static constexpr int RAW_FLOATS = RAW_ITEMS * 4;       // 6144 floats = 24 KB
-    static constexpr int LDS_FLOATS = 32 * EPI_TILE;       // the epilogue holds all 32 tiles at once (144 KB)
+    static constexpr int LDS_FLOATS = 2 * V_FLOATS + 2 * RAW_FLOATS;      // 144 KB: both V buffers, both raw images
     static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
-    static_assert(2 * V_FLOATS + 2 * RAW_FLOATS <= LDS_FLOATS, "both V buffers and both raw images fit");
 };
 
 __device__ __forceinline__ float4 w2sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
@@ -75,11 +74,6 @@ __device__ __forceinline__ float4 w2add(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float2 w2sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 w2add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 
-// CUs of the device (gfx950: 256): the stride between a block and the one that follows it on its CU; 0 = no
-// warming of the next block's first halo images
-#ifndef SIV_W2_CUS
-#define SIV_W2_CUS 256
-#endif
 #ifndef SIV_W2ROUNDS
 #define SIV_W2ROUNDS 1
 #endif
@@ -87,13 +81,20 @@ __device__ __forceinline__ float2 w2add(float2 a, float2 b) { return make_float2
 // TPR = tiles per row of a brick plane: 4 (8 x 8 voxels, 16 tiles) or 5 (6 x 10 voxels, 15 tiles: slot 15
 // empty).  ROUNDS = 1: a staging item is (tile-row, channel pair), 384 items = waves 0..5; ROUNDS = 2: an item
 // is (tile-row, channel quad) handled as two pairs in turn, 192 items = waves 0..2.
+//
+// A block works through the bricks blockIdx.x, blockIdx.x + gridDim.x, ... (nbricks in all) as ONE stream of
+// chunks: the raw image two chunks ahead and the transformed image one chunk ahead belong to the next brick
+// when the current one runs out, so only the first brick of a block pays the prologue (a first global load
+// that nothing covers, ~5 % of a brick).  Between two bricks the epilogue runs in two halves inside the 72 KB
+// of LDS that the next brick's images do not occupy.  The launcher chains bricks only for an even chunk count
+// of at least four (buffer parities then repeat per brick); otherwise gridDim.x = nbricks.
 template <int TPR, int ROUNDS>
 __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict__ x,
                                                         const float* __restrict__ wp,
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ y, int N, int D, int H, int W,
                                                         int Cin, int Cout, int nbd, int nbh, int nbw,
-                                                        float* __restrict__ stat_part) {
+                                                        int nbricks, float* __restrict__ stat_part) {
     using C = W2Cfg;
     constexpr int tpr = TPR, trows = 16 / TPR;
     constexpr int BHP = 2 * trows + 2, BWP = 2 * TPR + 2;      // halo plane: 10 x 10 or 8 x 12 voxels
@@ -101,6 +102,10 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     static_assert(2 * NV <= C::RAW_ITEMS, "three 16-byte items per thread cover the halo");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const rimg = lds + 2 * C::V_FLOATS;                 // two raw halo images
+    // between two bricks V[0] holds the next brick's chunk 0 and raw image 1 its chunk 1: the epilogue has
+    // V[1] and raw image 0, 72 KB in one piece = 16 exchange tiles
+    float* const epi = lds + C::V_FLOATS;
+    static_assert(C::V_FLOATS + C::RAW_FLOATS == 16 * C::EPI_TILE, "half of the exchange tiles fit between the live images");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -108,16 +113,17 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     const int ph = wave & 3, wn = wave >> 2;
     SIV_STAMP(0);
 
-    // brick of a block index: each XCD (blockIdx.x mod 8) walks a contiguous eighth of the bricks
+    // brick of a dispatch index: each XCD (index mod 8) walks a contiguous eighth of the bricks
     auto brick_of = [&](int b, int& bn, int& bz0, int& by0, int& bx0) {
-        if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+        if ((nbricks & 7) == 0) b = (b & 7) * (nbricks >> 3) + (b >> 3);
         const int bx = b % nbw; b /= nbw;
         const int by = b % nbh; b /= nbh;
         bz0 = (b % nbd) * C::BD; by0 = by * 2 * trows; bx0 = bx * 2 * tpr;
         bn = b / nbd;
     };
+    int vb = blockIdx.x;
     int n, z0, y0, x0;
-    brick_of(blockIdx.x, n, z0, y0, x0);
+    brick_of(vb, n, z0, y0, x0);
     const int co0 = blockIdx.y * C::NT;
     const int nchunk = Cin / C::CK;
 
@@ -139,14 +145,20 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
 
     // ---- raw halo image: the 8 channels of a chunk of every halo voxel, [voxel][8], zeros outside the
     // volume.  Item i = p*512 + tid is half (i & 1) of voxel i >> 1: every wave fetches three 16-byte
-    // items per chunk with plain coalesced loads (pairs of lanes read 32 contiguous bytes) one chunk ahead
+    // items per chunk with plain coalesced loads (pairs of lanes read 32 contiguous bytes) two chunks ahead
     // and stores them ten taps later; the overlapping 4x4 patches are then cut out of LDS.
-    const __amdgpu_buffer_rsrc_t xrs = buf_rsrc(x + (long)n * D * H * W * Cin, (long)D * H * W * Cin * 4);
+    const long sample = (long)D * H * W * Cin;
+    __amdgpu_buffer_rsrc_t xrs = buf_rsrc(x + n * sample, sample * 4);       // sample of the brick being fetched
     unsigned roff[3];
+    // (`opaque`: a copy of tid the compiler cannot see through, so that what depends only on the lane is
+    // recomputed where it is used -- once per brick -- instead of living in registers through the chunk loop,
+    // where there are none to spare)
+    auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
     auto halo_offsets = [&](int bz0, int by0, int bx0) {
+        const int tid_ = opaque(tid);
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            const int i = p * C::NTHR + tid, v = i >> 1;
+            const int i = p * C::NTHR + tid_, v = i >> 1;
             const int hx = v % BWP, hy = (v / BWP) % BHP, hz = v / (BWP * BHP);
             const int gz = bz0 - 1 + hz, gy = by0 - 1 + hy, gx = bx0 - 1 + hx;
             const bool ok = v < NV && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -158,19 +170,6 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     auto load_raw = [&](int c0) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) raw[p] = buf_load16(xrs, roff[p], c0 * 4);
-    };
-    // The block that follows this one on its CU (blocks start in index order, one per CU) waits for its
-    // first two halo images with nothing to do.  The last two chunks of this block have no image left to
-    // fetch for themselves, so their fetch slots touch that block's first two images instead: the data
-    // lands in the L2 of the XCD both blocks run on (the stride is a multiple of 8).
-    const long lin_next = (long)blockIdx.y * gridDim.x + blockIdx.x + SIV_W2_CUS;
-    const bool warm = SIV_W2_CUS > 0 && nchunk >= 3 && lin_next < (long)gridDim.x * gridDim.y;
-    int nn = n, nz0 = z0, ny0 = y0, nx0 = x0;
-    if (warm) brick_of((int)(lin_next % gridDim.x), nn, nz0, ny0, nx0);
-    const __amdgpu_buffer_rsrc_t xrs_next = buf_rsrc(x + (long)nn * D * H * W * Cin, (long)D * H * W * Cin * 4);
-    auto load_raw_next = [&](int c0) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) raw[p] = buf_load16(xrs_next, roff[p], c0 * 4);
     };
     auto store_raw = [&](float* img) {
 #pragma unroll
@@ -218,20 +217,11 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
         }
     };
 
-    // ---- prologue: raw image 0 -> V buffer 0, raw image 1, the first weight fragments
-    // (both images are requested before either is waited for)
+    // ---- prologue (first brick of the block only): raw image 0 -> V buffer 0, raw image 1, the first weight
+    // fragments (both images are requested before either is waited for)
     load_raw(0);
     f32x16 acc[4][2];          // [pw][row tile]
-    {
-        float4 raw1[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) raw1[p] = buf_load16(xrs, roff[p], (nchunk > 1 ? 1 : 0) * C::CK * 4);
-#pragma unroll
-        for (int i = 0; i < PD; ++i) bring[i] = buf_load16(wrs, wvo, wso0 + ((i >> 2) * 16 + (i & 3)) * C::SLICE * 4);
-        static_assert(12 % PD == 0, "ring index must not depend on the chunk");
-        // the accumulators are cleared here, under the latency of the first loads: 128 vector instructions
-        // per wave that would otherwise sit between the prologue's last barrier and the first matrix instruction
-        __builtin_amdgcn_sched_barrier(0);
+    auto clear_acc = [&]() {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -242,6 +232,18 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int a = 0; a < 2; ++a) asm volatile("" : "+v"(acc[p][a]));
+    };
+    {
+        float4 raw1[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) raw1[p] = buf_load16(xrs, roff[p], (nchunk > 1 ? 1 : 0) * C::CK * 4);
+#pragma unroll
+        for (int i = 0; i < PD; ++i) bring[i] = buf_load16(wrs, wvo, wso0 + ((i >> 2) * 16 + (i & 3)) * C::SLICE * 4);
+        static_assert(12 % PD == 0, "ring index must not depend on the chunk");
+        // the accumulators are cleared here, under the latency of the first loads: 128 vector instructions
+        // per wave that would otherwise sit between the prologue's last barrier and the first matrix instruction
+        __builtin_amdgcn_sched_barrier(0);
+        clear_acc();
         __builtin_amdgcn_sched_barrier(0);
         store_raw(rimg);
 #pragma unroll
@@ -259,151 +261,166 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
         }
     }
     __syncthreads();
-    SIV_STAMP(2);
 
-    for (int cc = 0; cc < nchunk; ++cc) {
-        const float* cur = lds + (cc & 1) * C::V_FLOATS;
-        float* nxt = lds + ((cc + 1) & 1) * C::V_FLOATS;
-        const float* rcur = rimg + ((cc + 1) & 1) * C::RAW_FLOATS;     // raw image of chunk cc + 1
-        float* rnxt = rimg + (cc & 1) * C::RAW_FLOATS;                 // receives chunk cc + 2
-        const bool more = cc + 1 < nchunk;
-        const int wso = wso0 + cc * C::TAPS * C::SLICE * 4;
-        float4 anext[2];
+    for (;;) {
+        // the brick after this one (chained launches only: gridDim.x < nbricks)
+        const int vnext = vb + (int)gridDim.x;
+        const bool has_next = vnext < nbricks;
+        int nn = n, nz0 = z0, ny0 = y0, nx0 = x0;
+        if (has_next) brick_of(vnext, nn, nz0, ny0, nx0);
+        SIV_STAMP(2);
+
+        for (int cc = 0; cc < nchunk; ++cc) {
+            const float* cur = lds + (cc & 1) * C::V_FLOATS;
+            float* nxt = lds + ((cc + 1) & 1) * C::V_FLOATS;
+            const float* rcur = rimg + ((cc + 1) & 1) * C::RAW_FLOATS;     // raw image of the next chunk of the stream
+            float* rnxt = rimg + (cc & 1) * C::RAW_FLOATS;                 // receives the chunk after next
+            const bool more = cc + 1 < nchunk || has_next;
+            const int wso = wso0 + cc * C::TAPS * C::SLICE * 4;
+            // the ring runs into the next chunk's slices: chunk 0 again behind the last chunk of a brick
+            const int wsn = cc + 1 < nchunk ? wso + C::TAPS * C::SLICE * 4 : has_next ? wso0 : wso + C::TAPS * C::SLICE * 4;
+            float4 anext[2];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) anext[a] = *reinterpret_cast<const float4*>(cur + aoff0 + a * 256);
+            for (int a = 0; a < 2; ++a) anext[a] = *reinterpret_cast<const float4*>(cur + aoff0 + a * 256);
 #pragma unroll
-        for (int t = 0; t < 12; ++t) {                     // t = kd*4 + pw
-            const int pw = t & 3;
-            float4 av[2];
-            const float4 bv = bring[t % PD];
+            for (int t = 0; t < 12; ++t) {                     // t = kd*4 + pw
+                const int pw = t & 3;
+                float4 av[2];
+                const float4 bv = bring[t % PD];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) av[a] = anext[a];
-            {   // fragment of tap t + PD (running into the next chunk at the end of this one)
-                const int tn = t + PD;
-                const int sl = tn < 12 ? (tn >> 2) * 16 + (tn & 3) : C::TAPS + ((tn - 12) >> 2) * 16 + ((tn - 12) & 3);
-                bring[t % PD] = buf_load16(wrs, wvo, wso + sl * C::SLICE * 4);
-            }
-            if (t + 1 < 12) {
-                const int t1 = t + 1;
-                const int tapoff = (t1 & 3) * C::PLANE + (t1 >> 2) * 128;
-                const int abase = (t1 >> 2) == 1 ? aoff1 : aoff0;
+                for (int a = 0; a < 2; ++a) av[a] = anext[a];
+                {   // fragment of tap t + PD
+                    const int tn = t + PD;
+                    bring[t % PD] = tn < 12 ? buf_load16(wrs, wvo, wso + ((tn >> 2) * 16 + (tn & 3)) * C::SLICE * 4)
+                                            : buf_load16(wrs, wvo, wsn + (((tn - 12) >> 2) * 16 + ((tn - 12) & 3)) * C::SLICE * 4);
+                }
+                if (t + 1 < 12) {
+                    const int t1 = t + 1;
+                    const int tapoff = (t1 & 3) * C::PLANE + (t1 >> 2) * 128;
+                    const int abase = (t1 >> 2) == 1 ? aoff1 : aoff0;
 #pragma unroll
-                for (int a = 0; a < 2; ++a) anext[a] = *reinterpret_cast<const float4*>(cur + abase + a * 256 + tapoff);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int a = 0; a < 2; ++a) anext[a] = *reinterpret_cast<const float4*>(cur + abase + a * 256 + tapoff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #define SIV_W2STEP(F)                                                                       \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                           \
         acc[pw][a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].F, bv.F, acc[pw][a], 0, 0, 0);
-            SIV_W2STEP(x)
-            SIV_W2STEP(y)
-            SIV_W2STEP(z)
-            SIV_W2STEP(w)
+                SIV_W2STEP(x)
+                SIV_W2STEP(y)
+                SIV_W2STEP(z)
+                SIV_W2STEP(w)
 #undef SIV_W2STEP
-            __builtin_amdgcn_sched_barrier(0);
-            // the raw image of the chunk after next: fetched now, stored at tap 10 (every wave)
-            if (t == 0) {
-                if (cc + 2 < nchunk) load_raw((cc + 2) * C::CK);
-                else if (warm) load_raw_next((cc + 2 - nchunk) * C::CK);
-            }
-            if (t == 10) store_raw(rnxt);
-            if (t == 11 && warm && cc + 3 == nchunk) halo_offsets(nz0, ny0, nx0);
-            if (t == 11 && warm && cc + 1 == nchunk) load_raw_next(2 * C::CK);     // third image: touched, never stored
-            // chunk cc + 1: patch reads one tap ahead of the first piece, two pieces per tap
-            if (more && s_on) {
-                if (ROUNDS == 2) {
-                    if (t == 0) read_patch(rcur, 0);
-                    if (t >= 1 && t <= 4) { stage_piece(2 * t - 2, 0, nxt); stage_piece(2 * t - 1, 0, nxt); }
-                    if (t == 5) read_patch(rcur, 1);
-                    if (t >= 6 && t <= 9) { stage_piece(2 * t - 12, 1, nxt); stage_piece(2 * t - 11, 1, nxt); }
-                } else {
-                    if (t == 5) read_patch(rcur, 0);
-                    if (t == 6) { stage_piece(0, 0, nxt); stage_piece(1, 0, nxt); }
-                    if (t == 7) { stage_piece(2, 0, nxt); stage_piece(3, 0, nxt); }
-                    if (t >= 8) stage_piece(t - 4, 0, nxt);
+                __builtin_amdgcn_sched_barrier(0);
+                // the raw image two chunks down the stream: fetched now, stored at tap 10 (every wave).  From
+                // the second-last chunk of a brick on it belongs to the next brick (offsets switched at the
+                // end of the chunk before).
+                if (t == 0) {
+                    if (cc + 2 < nchunk) load_raw((cc + 2) * C::CK);
+                    else if (has_next) load_raw((cc + 2 - nchunk) * C::CK);
+                }
+                if (t == 10) store_raw(rnxt);
+                if (t == 11 && has_next && cc + 3 == nchunk) {
+                    halo_offsets(nz0, ny0, nx0);
+                    xrs = buf_rsrc(x + nn * sample, sample * 4);
+                }
+                // next chunk of the stream: patch reads one tap ahead of the first piece, two pieces per tap
+                if (more && s_on) {
+                    if (ROUNDS == 2) {
+                        if (t == 0) read_patch(rcur, 0);
+                        if (t >= 1 && t <= 4) { stage_piece(2 * t - 2, 0, nxt); stage_piece(2 * t - 1, 0, nxt); }
+                        if (t == 5) read_patch(rcur, 1);
+                        if (t >= 6 && t <= 9) { stage_piece(2 * t - 12, 1, nxt); stage_piece(2 * t - 11, 1, nxt); }
+                    } else {
+                        if (t == 5) read_patch(rcur, 0);
+                        if (t == 6) { stage_piece(0, 0, nxt); stage_piece(1, 0, nxt); }
+                        if (t == 7) { stage_piece(2, 0, nxt); stage_piece(3, 0, nxt); }
+                        if (t >= 8) stage_piece(t - 4, 0, nxt);
+                    }
                 }
             }
+            SIV_STAMP(3 + 2 * cc);
+            __syncthreads();
+            SIV_STAMP(4 + 2 * cc);
         }
-        SIV_STAMP(3 + 2 * cc);
-        __syncthreads();
-        SIV_STAMP(4 + 2 * cc);
-    }
 
-    // ---- output transform and store ----
-    // along W on the accumulators: Z[ow] = sum_pw At[ow][pw] M[ph][pw]
-    const int cq = lane & 7;
-    const int co = co0 + wn * 32 + 4 * cq;
-    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias && co < Cout) bq = *reinterpret_cast<const float4*>(bias + co);
-    const int oh = ph & 1, ow = ph >> 1;                   // the output parity this wave combines and stores
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // tiles E[((ph*2 + wn)*2 + ow')*2 + a] of 32 rows x 32 channels: all 32 at once, one barrier
+        // ---- output transform and store, one row tile (a) at a time ----
+        // along W on the accumulators: Z[ow'] = sum_pw At[ow'][pw] M[ph][pw]; along H across the four ph waves
+        // through the exchange tiles E[(ph*2 + wn)*2 + ow'] of 32 rows x 32 channels: oh = 0: Z0 + Z1 + Z2,
+        // oh = 1: Z1 - Z2 - Z3
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int tid_ = opaque(tid);                          // lane-only quantities: recomputed per brick
+        const int lane = tid_ & 63, wave = tid_ >> 6;
+        const int li = lane & 31, lh = lane >> 5;
+        const int ph = wave & 3, wn = wave >> 2;
+        const int cq = lane & 7;
+        const int co = co0 + wn * 32 + 4 * cq;
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && co < Cout) bq = *reinterpret_cast<const float4*>(bias + co);
+        const int oh = ph & 1, ow = ph >> 1;                   // the output parity this wave combines and stores
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < 2; ++a) {
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            float* tile = lds + (((ph * 2 + wn) * 2 + o) * 2 + a) * C::EPI_TILE;
+            for (int o = 0; o < 2; ++o) {
+                float* tile = epi + ((ph * 2 + wn) * 2 + o) * C::EPI_TILE;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = o == 0 ? (acc[0][a][r] + acc[1][a][r]) + acc[2][a][r]
-                                       : (acc[1][a][r] - acc[2][a][r]) - acc[3][a][r];
-                tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * C::EPI_STRIDE + li] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const float v = o == 0 ? (acc[0][a][r] + acc[1][a][r]) + acc[2][a][r]
+                                           : (acc[1][a][r] - acc[2][a][r]) - acc[3][a][r];
+                    tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * C::EPI_STRIDE + li] = v;
+                }
             }
-        }
-    }
-    __syncthreads();
-    // along H across the four ph waves: oh = 0: Z0 + Z1 + Z2, oh = 1: Z1 - Z2 - Z3
+            if (a == 1 && has_next) clear_acc();           // for the next brick, while the others catch up
+            __syncthreads();
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int row = ps * 8 + (lane >> 3);
-            const int off = row * C::EPI_STRIDE + 4 * cq;
-            const float4 za = *reinterpret_cast<const float4*>(lds + ((((oh + 0) * 2 + wn) * 2 + ow) * 2 + a) * C::EPI_TILE + off);
-            const float4 zb = *reinterpret_cast<const float4*>(lds + ((((oh + 1) * 2 + wn) * 2 + ow) * 2 + a) * C::EPI_TILE + off);
-            const float4 zc = *reinterpret_cast<const float4*>(lds + ((((oh + 2) * 2 + wn) * 2 + ow) * 2 + a) * C::EPI_TILE + off);
-            float4 v = oh == 0 ? w2add(w2add(za, zb), zc) : w2sub(w2sub(za, zb), zc);
-            const int m = a * 32 + row;
-            const int et = (m & 15) / tpr;
-            const int gz = z0 + (m >> 4), gy = y0 + 2 * et + oh, gx = x0 + 2 * ((m & 15) - et * tpr) + ow;
-            if (et < trows && gz < D && gy < H && gx < W && co < Cout) {
-                s1 = w2add(s1, v);
-                s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
-                s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
-                v = w2add(v, bq);
-                *reinterpret_cast<float4*>(y + ((((long)n * D + gz) * H + gy) * W + gx) * Cout + co) = v;
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + (lane >> 3);
+                const int off = row * C::EPI_STRIDE + 4 * cq;
+                const float4 za = *reinterpret_cast<const float4*>(epi + (((oh + 0) * 2 + wn) * 2 + ow) * C::EPI_TILE + off);
+                const float4 zb = *reinterpret_cast<const float4*>(epi + (((oh + 1) * 2 + wn) * 2 + ow) * C::EPI_TILE + off);
+                const float4 zc = *reinterpret_cast<const float4*>(epi + (((oh + 2) * 2 + wn) * 2 + ow) * C::EPI_TILE + off);
+                float4 v = oh == 0 ? w2add(w2add(za, zb), zc) : w2sub(w2sub(za, zb), zc);
+                const int m = a * 32 + row;
+                const int et = (m & 15) / tpr;
+                const int gz = z0 + (m >> 4), gy = y0 + 2 * et + oh, gx = x0 + 2 * ((m & 15) - et * tpr) + ow;
+                if (et < trows && gz < D && gy < H && gx < W && co < Cout) {
+                    s1 = w2add(s1, v);
+                    s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
+                    s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+                    v = w2add(v, bq);
+                    *reinterpret_cast<float4*>(y + ((((long)n * D + gz) * H + gy) * W + gx) * Cout + co) = v;
+                }
             }
+            __syncthreads();                   // the tiles have been read
         }
-    }
-    SIV_STAMP(29);
-    if (warm) {
+        SIV_STAMP(29);
+        if (stat_part) {
+            // lanes with equal cq (bits 3..5 differ) hold the same four channels
 #pragma unroll
-        for (int p = 0; p < 3; ++p) asm volatile("" ::"v"(raw[p].x), "v"(raw[p].y), "v"(raw[p].z), "v"(raw[p].w));     // keeps the touching loads alive
-    }
-    if (stat_part) {
-        // lanes with equal cq (bits 3..5 differ) hold the same four channels
+            for (int o = 8; o < 64; o <<= 1) {
+                s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64);
+                s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+                s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64);
+                s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+            }
+            float* red = epi;                  // [8 waves][2 (sum, sumsq)][32 channels]
+            if (lane < 8) {
+                *reinterpret_cast<float4*>(red + (wave * 2 + 0) * 32 + 4 * cq) = s1;
+                *reinterpret_cast<float4*>(red + (wave * 2 + 1) * 32 + 4 * cq) = s2;
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const int k = tid >> 6, c = tid & 63, w0 = (c >> 5) * 4;
+                float s = 0.f;
 #pragma unroll
-        for (int o = 8; o < 64; o <<= 1) {
-            s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64);
-            s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
-            s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64);
-            s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+                for (int p = 0; p < 4; ++p) s += red[((w0 + p) * 2 + k) * 32 + (c & 31)];
+                if (co0 + c < Cout) stat_part[((long)vb * 2 + k) * Cout + co0 + c] = s;
+            }
+            __syncthreads();                   // before the next brick's staging writes here
         }
-        __syncthreads();                   // the tiles have been read
-        float* red = lds;                  // [8 waves][2 (sum, sumsq)][32 channels]
-        if (lane < 8) {
-            *reinterpret_cast<float4*>(red + (wave * 2 + 0) * 32 + 4 * cq) = s1;
-            *reinterpret_cast<float4*>(red + (wave * 2 + 1) * 32 + 4 * cq) = s2;
-        }
-        __syncthreads();
-        if (tid < 128) {
-            const int k = tid >> 6, c = tid & 63, w0 = (c >> 5) * 4;
-            float s = 0.f;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) s += red[((w0 + p) * 2 + k) * 32 + (c & 31)];
-            if (co0 + c < Cout) stat_part[((long)blockIdx.x * 2 + k) * Cout + co0 + c] = s;
-        }
+        SIV_STAMP(30);
+        if (!has_next) break;
+        vb = vnext; n = nn; z0 = nz0; y0 = ny0; x0 = nx0;
     }
-    SIV_STAMP(30);
 }
 
 // Packed, transformed weights: wp[ct][cc][kd*16 + ph*4 + pw][co (64)][ci (8)] = (G g_kd G^T)[ph][pw].
@@ -442,6 +459,12 @@ __global__ __launch_bounds__(256) void k3_pack_weights_wino2d(const float* __res
     }
 }
 
+// SIV_W2CHAIN=0 (build flag) launches one block per brick as before
+#ifndef SIV_W2CHAIN
+#define SIV_W2CHAIN 1
+#endif
+constexpr bool W2_CHAIN = SIV_W2CHAIN != 0;
+constexpr long W2_CUS = 256;           // CUs of the device (gfx950)
 bool k3_fwd_wino2d_supported(int Cin, int Cout) { return Cin % 8 == 0 && Cout % 64 == 0; }
 size_t k3_fwd_wino2d_ws_bytes(int Cin, int Cout) {     // one chunk of padding behind the last slice
     return ((size_t)(Cout / 64) * (Cin / 8) + 1) * 48 * 512 * sizeof(float);
@@ -472,10 +495,19 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
     }
     const int tpr = w2d_tpr(H, W);
     const int nbd = (D + 3) / 4, nbh = (int)cdiv(H, 2 * (16 / tpr)), nbw = (int)cdiv(W, 2 * tpr);
-    const long nblk = (long)N * nbd * nbh * nbw;
-    if (nblk > 0x7fffffffL) {
+    const long nbricks = (long)N * nbd * nbh * nbw;
+    if (nbricks > 0x7fffffffL) {
         set_error("conv3d_k3(winograd 2-D): too many bricks");
         return SIV_EINVAL;
+    }
+    // One block per CU working through its bricks as one chunk stream, where the stream's buffer parities
+    // repeat per brick (even chunk count) and a brick is long enough to fetch two chunks ahead inside it;
+    // the grid's x extent stays a multiple of 8 so that a block's bricks share its XCD.
+    long nblk = nbricks;
+    const int nchunk = Cin / 8, ncot = Cout / 64;
+    if (W2_CHAIN && nchunk >= 4 && nchunk % 2 == 0 && nbricks * ncot > W2_CUS) {
+        long g = (W2_CUS / ncot) & ~7L;
+        if (g >= 8 && g < nbricks) nblk = g;
     }
     auto kern = tpr == 5 ? k3_fwd_wino2d<5, SIV_W2ROUNDS> : k3_fwd_wino2d<4, SIV_W2ROUNDS>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -484,7 +516,7 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
         return SIV_EHIP;
     }
     kern<<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 512, W2Cfg::LDS_BYTES, s>>>(
-        x, wpk, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part);
+        x, wpk, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, (int)nbricks, stat_part);
     SIV_CHECK_LAUNCH("conv3d_k3(winograd 2-D)");
     return SIV_OK;
 }

@@ -30,10 +30,11 @@ int main() {
     printf("%.3f ms per launch (with stamps)\n", ms);
     std::vector<unsigned long long> st(2048 * 8 * 32);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(siv::w2_stamps), st.size() * 8);
-    // per block: use the LAST launch's stamps; statistics over blocks 256..2047 (steady state)
+    // per block: the stamps of the LAST brick of the last launch (a block runs its bricks as one chunk stream;
+    // stamp 2 = start of that brick's chunk loop, stamps 0/1 = the block's prologue)
     auto at = [&](int b, int wv, int i) { return (double)st[((size_t)b * 8 + wv) * 32 + i]; };
     double pro = 0, epi = 0, tot = 0, chunk[8] = {0}, wait[9] = {0}, waitw[8] = {0}, cnt = 0;
-    for (int b = 256; b < 2048; ++b) {
+    for (int b = 0; b < 256; ++b) {
         double t0 = 1e30, tend = 0;
         for (int wv = 0; wv < 8; ++wv) { t0 = std::min(t0, at(b, wv, 0)); tend = std::max(tend, at(b, wv, 30)); }
         tot += tend - t0;
