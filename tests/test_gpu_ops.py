@@ -112,6 +112,12 @@ CONV_CASES = [
     # extents, 10- and 20-wide low-resolution volumes, three samples
     (8, 64, (6, 10, 14), 2, 2, 6), (16, 64, (6, 26, 18), 1, 2, 6), (24, 64, (2, 2, 2), 3, 2, 6),
     (64, 128, (4, 24, 40), 1, 2, 6), (16, 64, (10, 24, 20), 1, 2, 6),
+    # ... with more bricks than CUs, so that a block of the 2-D Winograd kernel chains several bricks into one
+    # chunk stream: uneven brick counts per block (375, 315 bricks on 256 blocks), brick counts that are not a
+    # multiple of 8 (no XCD remap), four and eight chunks, 6 x 10-voxel brick planes (264 bricks), two
+    # output-channel tiles (144 bricks x 2 on 128 x 2 blocks); forward and input gradient
+    (32, 64, (20, 24, 40), 5, 1, 6), (64, 64, (12, 24, 40), 7, 1, 6), (64, 64, (12, 24, 20), 11, 1, 6),
+    (64, 128, (16, 24, 24), 4, 1, 6),
     # the same wide shapes through the generic kernels (cross-check of the dispatcher)
     (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
 ]
@@ -451,6 +457,8 @@ def test_add_act(B, shape):
     (64, 64, (8, 12, 8), 2, 1, 5, False), (8, 64, (5, 7, 9), 3, 1, 5, True),   # ... and the split-bf16 kernels
     (64, 128, (8, 8, 16), 1, 2, 5, True), (16, 64, (10, 24, 20), 1, 2, 5, False),
     (64, 64, (8, 12, 8), 2, 1, 6, False), (8, 64, (5, 7, 9), 3, 1, 6, True), (16, 128, (10, 24, 20), 1, 1, 6, True),
+    # ... from chained bricks (375 bricks on 256 blocks: a block emits the rows of all its bricks)
+    (32, 64, (20, 24, 40), 5, 1, 6, True),
     # ... and the product form of the upsampled kernel (forced by path 6; one-plane bricks, 20-wide variant)
     (64, 128, (8, 8, 16), 1, 2, 6, True), (16, 64, (10, 24, 20), 1, 2, 6, False), (8, 64, (6, 10, 14), 2, 2, 6, True),
     (4, 8, (6, 7, 5), 2, 1, 0, True), (1, 8, (8, 12, 8), 2, 1, 0, True), (64, 64, (10, 12, 10), 1, 1, 0, False),
