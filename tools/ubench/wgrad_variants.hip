@@ -3,6 +3,7 @@
 namespace siv {
 void set_error(const char*, ...) {}
 int conv_path() { return 0; }
+void* pack_slot(const void*, int, int, int, int, int, size_t, void* ws, bool* need) { *need = true; return ws; }
 }
 int main() {
     const int N = 8, D = 80, H = 96, W = 80, C = 64;
