@@ -74,6 +74,10 @@ __device__ __forceinline__ float4 w2add(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float2 w2sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 w2add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 
+// tap at which the staging of the next chunk starts (patch reads; the eight pieces follow over six taps)
+#ifndef SIV_W2STAGE_T0
+#define SIV_W2STAGE_T0 5
+#endif
 #ifndef SIV_W2ROUNDS
 #define SIV_W2ROUNDS 1
 #endif
@@ -331,10 +335,11 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
                         if (t == 5) read_patch(rcur, 1);
                         if (t >= 6 && t <= 9) { stage_piece(2 * t - 12, 1, nxt); stage_piece(2 * t - 11, 1, nxt); }
                     } else {
-                        if (t == 5) read_patch(rcur, 0);
-                        if (t == 6) { stage_piece(0, 0, nxt); stage_piece(1, 0, nxt); }
-                        if (t == 7) { stage_piece(2, 0, nxt); stage_piece(3, 0, nxt); }
-                        if (t >= 8) stage_piece(t - 4, 0, nxt);
+                        constexpr int T0 = SIV_W2STAGE_T0;
+                        if (t == T0) read_patch(rcur, 0);
+                        if (t == T0 + 1) { stage_piece(0, 0, nxt); stage_piece(1, 0, nxt); }
+                        if (t == T0 + 2) { stage_piece(2, 0, nxt); stage_piece(3, 0, nxt); }
+                        if (t >= T0 + 3 && t <= T0 + 6) stage_piece(t - T0 + 1, 0, nxt);
                     }
                 }
             }
