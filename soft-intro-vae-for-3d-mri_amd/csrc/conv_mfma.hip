@@ -371,6 +371,11 @@ int k3_fwd_mfma_launch(const float* x, const float* w, const float* bias, float*
 // ---------------------------------------------------------------------------------
 // Block = (range of 2x4xBW-voxel bricks) x (one kd plane of taps) x (64 co x 64 ci tile).
 // Wave w owns co half (w&1), ci half (w>>1) and the 9 taps (kh,kw) of the plane.
+// MODE 1, 2 -- narrow layers (Cin <= 32 and Cout <= 32: the 16- and 32-channel full-resolution layers of the
+// FC-latent model): all channels fit one 32 x 32 sub-tile, which would leave three of the four waves idle, so
+// the waves split the brick's VOXELS instead (two of its eight rows each, a partial slab per wave); MODE 2
+// (Cin <= 16): the 32 columns of a tile hold two taps x 16 input channels, five matrix instructions per k-step
+// instead of nine.
 // BW = 8, or 10 for volumes whose width is a multiple of 10 but not of 8 (20, 10: the two
 // deepest levels of an 80x96x80 input) -- voxels are the K dimension, so padding is pure waste.
 template <int UPS, int BW_>
@@ -444,7 +449,7 @@ struct WgStage {
     }
 };
 
-template <int UPS, int BW_>
+template <int UPS, int BW_, int MODE>
 __global__ __launch_bounds__(256, 2) void k3_wgrad_mfma(const float* __restrict__ x,
                                                         const float* __restrict__ dy,
                                                         float* __restrict__ part, int N, int D, int H,
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void k3_wgrad_mfma(const float* __restrict_
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int cs = wave & 1, is = wave >> 1;
+    const int cs = MODE ? 0 : wave & 1, is = MODE ? 0 : wave >> 1;
     const int kd = blockIdx.y;
     const int ntci = (Cin + 63) / 64;
     const int co0 = (blockIdx.z / ntci) * 64, ci0 = (blockIdx.z % ntci) * 64;
@@ -485,7 +490,44 @@ __global__ __launch_bounds__(256, 2) void k3_wgrad_mfma(const float* __restrict_
             st.load(x, dy, br + 1, kd, co0, ci0, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
         const float* ap = dyl + lh * C::CP + cs * 32 + li;
         const float* bp = xl + lh * C::CP + is * 32 + li;
-        if (active)
+        if constexpr (MODE != 0) {
+            // this wave's rows 2 wave, 2 wave + 1 of the brick's BD x BH rows: BW / 2 k-steps each
+            constexpr int HB = C::BW / 2;
+            static_assert(C::BD * C::BH == 8, "two brick rows per wave");
+            const int row = 2 * wave;
+            const float* aw = ap + 2 * (row * HB) * C::CP;
+            const int wbase = ((row / C::BH) * C::HH + row % C::BH) * C::HW;
+            if constexpr (MODE == 2) {
+                // column li = (tap 2p + (li >> 4), input channel li & 15) of tile p; the odd half of tile 4 has no tap
+                const float* bq[5];
+#pragma unroll
+                for (int p2 = 0; p2 < 5; ++p2) {
+                    const int t = 2 * p2 + (li >> 4) < 9 ? 2 * p2 + (li >> 4) : 8;
+                    bq[p2] = xl + lh * C::CP + (li & 15) + (wbase + (t / 3) * C::HW + (t % 3)) * C::CP;
+                }
+#pragma unroll
+                for (int j = 0; j < 2 * HB; ++j) {
+                    const int off = ((j / HB) * C::HW + 2 * (j % HB)) * C::CP;
+                    const float a = aw[2 * j * C::CP];
+#pragma unroll
+                    for (int p2 = 0; p2 < 5; ++p2)
+                        acc[p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[p2][off], acc[p2], 0, 0, 0);
+                }
+            } else {
+                const float* bw = bp + wbase * C::CP;
+#pragma unroll 1
+                for (int jr = 0; jr < 2; ++jr) {                  // (one brick row at a time: register budget)
+#pragma unroll
+                    for (int jc = 0; jc < HB; ++jc) {
+                        const float a = aw[2 * (jr * HB + jc) * C::CP];
+#pragma unroll
+                        for (int t = 0; t < 9; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                a, bw[(jr * C::HW + 2 * jc + (t / 3) * C::HW + (t % 3)) * C::CP], acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        } else if (active)
 #pragma unroll 4
         for (int kk = 0; kk < C::M / 2; ++kk) {
             // voxels 2kk + lh: dx = 2*(kk % (BW/2)) + lh, dy = (kk / (BW/2)) % BH, dz = kk / (BW/2*BH)
@@ -500,8 +542,20 @@ __global__ __launch_bounds__(256, 2) void k3_wgrad_mfma(const float* __restrict_
         }
     }
 
-    // partial slab: part[blockIdx.x][co][tap][ci]
-    float* pp = part + (long)blockIdx.x * Cout * 27 * Cin;
+    // partial slab: part[blockIdx.x][co][tap][ci]; narrow layers: one slab per wave, part[blockIdx.x * 4 + wave]
+    float* pp = part + (MODE ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x) * Cout * 27 * Cin;
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int p2 = 0; p2 < 5; ++p2) {
+            const int t = 2 * p2 + (li >> 4), ci = li & 15;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < Cout && t < 9 && ci < Cin) pp[((long)co * 27 + kd * 9 + t) * Cin + ci] = acc[p2][r];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
 #pragma unroll
@@ -526,8 +580,18 @@ __global__ __launch_bounds__(256) void slab_reduce(const float* __restrict__ par
                                                    float* __restrict__ out, int accumulate) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long)gridDim.x * blockDim.x) {
+        // sixteen slabs in flight (a thread's loads are independent; added in slab order as before): with
+        // hundreds of slabs of a small tensor the loop is bound by load latency, not by bandwidth
         float s = 0.f;
-        for (int k = 0; k < nslab; ++k) s += part[(long)k * n + i];
+        int k = 0;
+        for (; k + 16 <= nslab; k += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = part[(long)(k + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; k < nslab; ++k) s += part[(long)k * n + i];
         out[i] = accumulate ? out[i] + s : s;
     }
 }
@@ -550,7 +614,9 @@ int k3_wgrad_mfma_launch(const float* x, const float* dy, float* dw, int N, int 
     long nsplit = 1024 / (3L * tiles);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > nbricks) nsplit = nbricks;
-    const long max_by_ws = (long)(ws_bytes / (wsize * sizeof(float)));
+    const int mode = (Cin <= 32 && Cout <= 32) ? (Cin <= 16 ? 2 : 1) : 0;
+    const int wave_slabs = mode ? 4 : 1;                            // narrow layers: a partial slab per wave
+    const long max_by_ws = (long)(ws_bytes / (wsize * sizeof(float))) / wave_slabs;
     if (nsplit > max_by_ws) nsplit = max_by_ws;
     if (nsplit < 1) {
         set_error("conv3d_k3_wgrad: workspace too small (need %zu, have %zu)",
@@ -560,19 +626,24 @@ int k3_wgrad_mfma_launch(const float* x, const float* dy, float* dw, int N, int 
     const int bpb = (int)cdiv(nbricks, nsplit);
     nsplit = cdiv(nbricks, bpb);
     dim3 grid((unsigned)nsplit, 3, (unsigned)tiles);
+#define SIV_WGM(U, BWW, MD)                                                                         \
+    k3_wgrad_mfma<U, BWW, MD><<<grid, 256, WgCfg<U, BWW>::LDS_BYTES, s>>>(x, dy, (float*)ws, N, D, H, W, Cin, \
+                                                                          Cout, nbd, nbh, nbw, bpb)
 #define SIV_WG(U, BWW)                                                                              \
-    k3_wgrad_mfma<U, BWW><<<grid, 256, WgCfg<U, BWW>::LDS_BYTES, s>>>(x, dy, (float*)ws, N, D, H, W, Cin, \
-                                                                      Cout, nbd, nbh, nbw, bpb)
+    do {                                                                                            \
+        if (mode == 2) SIV_WGM(U, BWW, 2); else if (mode == 1) SIV_WGM(U, BWW, 1); else SIV_WGM(U, BWW, 0); \
+    } while (0)
     if (ups == 1) {
         if (wide) SIV_WG(1, 10); else SIV_WG(1, 8);
     } else {
         if (wide) SIV_WG(2, 10); else SIV_WG(2, 8);
     }
 #undef SIV_WG
+#undef SIV_WGM
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(mfma)");
     long g = cdiv(wsize, 256);
     if (g > 4096) g = 4096;
-    slab_reduce<<<(unsigned)g, 256, 0, s>>>((const float*)ws, (int)nsplit, wsize, dw, accumulate);
+    slab_reduce<<<(unsigned)g, 256, 0, s>>>((const float*)ws, (int)nsplit * wave_slabs, wsize, dw, accumulate);
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(reduce)");
     return SIV_OK;
 }
