@@ -257,8 +257,18 @@ __global__ __launch_bounds__(512, 2) void k3_wgrad_wino2d(const float* __restric
 // part[0][e] = sum_s part[s][e] in fixed order (every thread owns its elements: safe in place)
 __global__ __launch_bounds__(256) void gw_sum_sets(float* __restrict__ part, int nsets, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        // eight sets in flight per thread (independent loads, added in set order): the loop is bound by load
+        // latency, and on the side stream it competes with the main stream's kernels for every CU it gets
         float s = 0.f;
-        for (int k = 0; k < nsets; ++k) s += part[(long)k * n + i];
+        int k = 0;
+        for (; k + 8 <= nsets; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(long)(k + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < nsets; ++k) s += part[(long)k * n + i];
         part[i] = s;
     }
 }
