@@ -754,6 +754,9 @@ int k2_up_fwd_launch(const float* x, const float* w, const float* bias, float* y
 //
 // Block = (range of 2x4xBW low-resolution bricks) x (parity class) x (64 co x 64 ci tile).
 // Wave w owns co half (w&1), ci half (w>>1) and the 8 collapsed taps.  Voxels are the K dimension.
+// MODE 1, 2 -- narrow layers (Cin <= 32 and Cout <= 32), as in k3_wgrad_mfma: the four waves split the
+// brick's voxels (two of its eight rows each, a partial slab per wave); MODE 2 (Cin <= 16): a tile's 32
+// columns hold two taps x 16 input channels, four matrix instructions per k-step instead of eight.
 template <int BW_>
 struct UwCfg {
     static constexpr int BD = 2, BH = 4, BW = BW_;
@@ -825,7 +828,7 @@ struct UwStage {
     }
 };
 
-template <int BW_>
+template <int BW_, int MODE>
 __global__ __launch_bounds__(256, 2) void k2_up_wgrad(const float* __restrict__ x,
                                                       const float* __restrict__ dy,
                                                       float* __restrict__ part, int N, int D, int H, int W,
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(256, 2) void k2_up_wgrad(const float* __restrict__ 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int cs = wave & 1, is = wave >> 1;
+    const int cs = MODE ? 0 : wave & 1, is = MODE ? 0 : wave >> 1;
     const int p = blockIdx.y, ad = p >> 2, ah = (p >> 1) & 1, aw = p & 1;
     const int ntci = (Cin + 63) / 64;
     const int co0 = (blockIdx.z / ntci) * 64, ci0 = (blockIdx.z % ntci) * 64;
@@ -865,7 +868,45 @@ __global__ __launch_bounds__(256, 2) void k2_up_wgrad(const float* __restrict__ 
             st.load(x, dy, br + 1, ad, ah, aw, co0, ci0, D, H, W, Cin, Cout, nbd, nbh, nbw);
         const float* ap = dyl + lh * C::CP + cs * 32 + li;
         const float* bp = xl + lh * C::CP + is * 32 + li;
-        if (active)
+        if constexpr (MODE != 0) {
+            // this wave's rows 2 wave, 2 wave + 1 of the brick's BD x BH rows: BW / 2 k-steps each
+            constexpr int HB = C::BW / 2;
+            static_assert(C::BD * C::BH == 8, "two brick rows per wave");
+            const int row = 2 * wave;
+            const float* aw_ = ap + 2 * (row * HB) * C::CP;
+            const int wbase = ((row / C::BH) * C::HH + row % C::BH) * C::HW;
+            if constexpr (MODE == 2) {
+                // column li = (tap 2 p2 + (li >> 4), input channel li & 15) of tile p2
+                const float* bq[4];
+#pragma unroll
+                for (int p2 = 0; p2 < 4; ++p2) {
+                    const int t = 2 * p2 + (li >> 4);
+                    bq[p2] = xl + lh * C::CP + (li & 15) + (wbase + ((t >> 2) * C::HH + ((t >> 1) & 1)) * C::HW + (t & 1)) * C::CP;
+                }
+#pragma unroll
+                for (int j = 0; j < 2 * HB; ++j) {
+                    const int off = ((j / HB) * C::HW + 2 * (j % HB)) * C::CP;
+                    const float a = aw_[2 * j * C::CP];
+#pragma unroll
+                    for (int p2 = 0; p2 < 4; ++p2)
+                        acc[p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[p2][off], acc[p2], 0, 0, 0);
+                }
+            } else {
+                const float* bw_ = bp + wbase * C::CP;
+#pragma unroll 1
+                for (int jr = 0; jr < 2; ++jr) {                  // (one brick row at a time: register budget)
+#pragma unroll
+                    for (int jc = 0; jc < HB; ++jc) {
+                        const float a = aw_[2 * (jr * HB + jc) * C::CP];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                a, bw_[(jr * C::HW + 2 * jc + ((t >> 2) * C::HH + ((t >> 1) & 1)) * C::HW + (t & 1)) * C::CP],
+                                acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        } else if (active)
 #pragma unroll 4
         for (int kk = 0; kk < C::M / 2; ++kk) {
             // voxels 2kk + lh: dx = 2*(kk % (BW/2)) + lh, dy = (kk / (BW/2)) % BH, dz = kk / (BW/2*BH)
@@ -880,8 +921,20 @@ __global__ __launch_bounds__(256, 2) void k2_up_wgrad(const float* __restrict__ 
         }
     }
 
-    // partial slab: part[blockIdx.x][co][p * 8 + s][ci]
-    float* pp = part + (long)blockIdx.x * Cout * 64 * Cin;
+    // partial slab: part[blockIdx.x][co][p * 8 + s][ci]; narrow layers: one slab per wave, part[blockIdx.x * 4 + wave]
+    float* pp = part + (MODE ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x) * Cout * 64 * Cin;
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+            const int t = 2 * p2 + (li >> 4), ci = li & 15;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < Cout && ci < Cin) pp[((long)co * 64 + p * 8 + t) * Cin + ci] = acc[p2][r];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -900,7 +953,15 @@ __global__ __launch_bounds__(256, 2) void k2_up_wgrad(const float* __restrict__ 
 __global__ __launch_bounds__(256) void slab_sum_inplace(float* __restrict__ part, int nslab, long n4) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 s = *reinterpret_cast<const float4*>(part + 4 * i);
-        for (int q = 1; q < nslab; ++q) {
+        int q = 1;
+        for (; q + 8 <= nslab; q += 8) {              // eight slabs in flight, added in slab order
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(part + (long)(q + u) * 4 * n4 + 4 * i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; q < nslab; ++q) {
             const float4 v = *reinterpret_cast<const float4*>(part + (long)q * 4 * n4 + 4 * i);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -942,7 +1003,9 @@ int k2_up_wgrad_launch(const float* x, const float* dy, float* dw, int N, int D,
     long nsplit = 1024 / (8L * tiles);
     if (nsplit < 1) nsplit = 1;
     if (nsplit > nbricks) nsplit = nbricks;
-    const long max_by_ws = (long)(ws_bytes / (wsize * sizeof(float)));
+    const int mode = (Cin <= 32 && Cout <= 32) ? (Cin <= 16 ? 2 : 1) : 0;
+    const int wave_slabs = mode ? 4 : 1;                            // narrow layers: a partial slab per wave
+    const long max_by_ws = (long)(ws_bytes / (wsize * sizeof(float))) / wave_slabs;
     if (nsplit > max_by_ws) nsplit = max_by_ws;
     if (nsplit < 1) {
         set_error("conv3d_k3_wgrad(upsampled): workspace too small (need %zu, have %zu)",
@@ -952,17 +1015,21 @@ int k2_up_wgrad_launch(const float* x, const float* dy, float* dw, int N, int D,
     const int bpb = (int)cdiv(nbricks, nsplit);
     nsplit = cdiv(nbricks, bpb);
     dim3 grid((unsigned)nsplit, 8, (unsigned)tiles);
-    if (wide)
-        k2_up_wgrad<10><<<grid, 256, UwCfg<10>::LDS_BYTES, s>>>(x, dy, (float*)ws, N, D, H, W, Cin, Cout, nbd, nbh,
-                                                                nbw, bpb);
-    else
-        k2_up_wgrad<8><<<grid, 256, UwCfg<8>::LDS_BYTES, s>>>(x, dy, (float*)ws, N, D, H, W, Cin, Cout, nbd, nbh,
-                                                              nbw, bpb);
+#define SIV_UWM(BWW, MD)                                                                            \
+    k2_up_wgrad<BWW, MD><<<grid, 256, UwCfg<BWW>::LDS_BYTES, s>>>(x, dy, (float*)ws, N, D, H, W, Cin, Cout, nbd, \
+                                                                  nbh, nbw, bpb)
+#define SIV_UW(BWW)                                                                                 \
+    do {                                                                                            \
+        if (mode == 2) SIV_UWM(BWW, 2); else if (mode == 1) SIV_UWM(BWW, 1); else SIV_UWM(BWW, 0);    \
+    } while (0)
+    if (wide) SIV_UW(10); else SIV_UW(8);
+#undef SIV_UW
+#undef SIV_UWM
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(upsampled)");
     long g = cdiv(wsize / 4, 256);        // Cin % 4 == 0: whole float4s
     if (g > 4096) g = 4096;
-    if (nsplit > 1) {
-        slab_sum_inplace<<<(unsigned)g, 256, 0, s>>>((float*)ws, (int)nsplit, wsize / 4);
+    if (nsplit * wave_slabs > 1) {
+        slab_sum_inplace<<<(unsigned)g, 256, 0, s>>>((float*)ws, (int)nsplit * wave_slabs, wsize / 4);
         SIV_CHECK_LAUNCH("conv3d_k3_wgrad(upsampled slab sum)");
     }
     g = cdiv((long)Cout * 27 * Cin, 256);

@@ -80,6 +80,9 @@ CONV_CASES = [
     # taps per 32-column tile when Cin <= 16: several bricks per block, ragged bricks, 10-wide bricks
     (16, 16, (16, 24, 40), 2, 1, 0), (16, 32, (8, 12, 20), 3, 1, 0), (32, 32, (9, 10, 11), 2, 1, 0),
     (32, 16, (8, 16, 16), 1, 1, 0), (8, 24, (7, 9, 13), 2, 1, 0), (12, 8, (6, 10, 10), 1, 1, 0),
+    # ... and behind an upsample (collapsed-tap weight gradient in its narrow modes; 10-wide low-resolution bricks)
+    (16, 16, (8, 16, 16), 2, 2, 0), (8, 32, (12, 8, 40), 1, 2, 0), (32, 16, (8, 8, 40), 2, 2, 0),
+    (16, 32, (16, 24, 40), 1, 2, 0),
     # widths 10 / 20 (the two deepest levels of an 80x96x80 input): 10-wide bricks in 3-wave blocks
     (8, 64, (10, 24, 20), 1, 1, 0), (16, 64, (10, 24, 20), 1, 2, 0), (8, 128, (5, 12, 10), 2, 1, 0),
     (64, 64, (10, 12, 10), 1, 1, 0), (8, 64, (4, 6, 10), 1, 2, 0),
