@@ -109,8 +109,8 @@ int siv_conv3d_k3_dgrad(const float* dy, const float* w, float* dx,
  * (models/models.py:57-59, models/mymodel.py:176-215), with respect to the LOW-RESOLUTION input:
  * dx[N][D/2][H/2][W/2][Cin] = 2x2x2 sum-pool of the gradient with respect to the upsampled tensor,
  * computed in one pass as a stride-2 convolution of dy[N][D][H][W][Cout] with the 4x4x4 kernel the
- * 27 taps collapse to (no full-resolution intermediate).  Needs Cin % 64 == 0, Cout % 8 == 0 and
- * 16-byte aligned pointers; siv_conv3d_k3_dgrad_up_supported returns 1 when the current conv path
+ * 27 taps collapse to (no full-resolution intermediate).  Needs Cin % 16 == 0 (tiles of 64 input
+ * channels, the last one may be partial), Cout % 8 == 0 and 16-byte aligned pointers; siv_conv3d_k3_dgrad_up_supported returns 1 when the current conv path
  * and the channel counts allow it, otherwise callers use siv_conv3d_k3_dgrad + siv_upsample2_bwd. */
 int siv_conv3d_k3_dgrad_up_supported(int Cin, int Cout);
 int siv_conv3d_k3_dgrad_up(const float* dy, const float* w, float* dx, int N, int D, int H, int W,

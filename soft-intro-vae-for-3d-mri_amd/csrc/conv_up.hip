@@ -646,10 +646,13 @@ __global__ __launch_bounds__(256) void k2_up_pack_weights_b3(const float* __rest
 
 static bool up_wide10(int W) { return (W / 2) % 10 == 0 && (W / 2) % 8 != 0; }
 
-bool k2_up_fwd_supported(int Cin, int Cout) { return Cin % 8 == 0 && Cout % 64 == 0; }
+// Output channels in tiles of 64; a last partial tile (the 16- and 32-channel layers of the FC-latent decoder)
+// is zero padded in the packed weights and masked in the stores (fp32 kernels; the split-bf16 packing needs
+// whole tiles).
+bool k2_up_fwd_supported(int Cin, int Cout) { return Cin % 8 == 0 && Cout % 16 == 0; }
 size_t k2_up_fwd_ws_bytes(int Cin, int Cout) {
     // sized for the split-bf16 packing (two 2 KB operand slices per tap), which is the larger one
-    return ((size_t)(Cout / 64) * 2 * (Cin / 8) * 32 + 4) * 4096;
+    return ((size_t)((Cout + 63) / 64) * 2 * (Cin / 8) * 32 + 4) * 4096;
 }
 // number of [2][Cout] partial-statistics rows the kernel emits (D, H, W: output extents)
 // the product form from 32 K output voxels upwards (and on request); its bricks hold one low-resolution plane
@@ -677,7 +680,7 @@ static int up_launch_prod(const float* x, const void* wp, const float* bias, flo
         set_error("conv3d_k3(upsampled): too many bricks");
         return SIV_EINVAL;
     }
-    k2_up_fwd_prod<LBD, LBH, LBW><<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 256, C::LDS_BYTES, s>>>(
+    k2_up_fwd_prod<LBD, LBH, LBW><<<dim3((unsigned)nblk, (unsigned)((Cout + 63) / 64)), 256, C::LDS_BYTES, s>>>(
         x, (const float*)wp, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, stat_part);
     SIV_CHECK_LAUNCH("conv3d_k3(upsampled, product form)");
     return SIV_OK;
@@ -693,7 +696,7 @@ static int up_launch_cfg(const float* x, const void* wp, const float* bias, floa
         set_error("conv3d_k3(upsampled): too many bricks");
         return SIV_EINVAL;
     }
-    const dim3 grid((unsigned)nblk, (unsigned)(Cout / 64));
+    const dim3 grid((unsigned)nblk, (unsigned)((Cout + 63) / 64));
     if (split)
         k2_up_fwd_b3<LBD, LBH, LBW><<<grid, 256, C::LDS_BYTES, s>>>(x, (const uint4*)wp, bias, y, N, D, H, W, Cin,
                                                                     Cout, nbd, nbh, nbw, stat_part);
@@ -711,9 +714,10 @@ int k2_up_fwd_launch(const float* x, const float* w, const float* bias, float* y
                      int W, int Cin, int Cout, void* ws, size_t ws_bytes, hipStream_t s, float* stat_part,
                      bool split, bool force_prod) {
     SIV_CHECK_WS(k2_up_fwd_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(upsampled)");
+    if (Cout % 64 != 0) split = false;
     bool need_pack;
     if (up_use_prod(N, D, H, W, split, force_prod)) {
-        const long total = (long)(Cout / 64) * 2 * (Cin / 8) * 18 * 512;
+        const long total = (long)((Cout + 63) / 64) * 2 * (Cin / 8) * 18 * 512;
         long g = cdiv(total, 256);
         if (g > 4096) g = 4096;
         void* wpk = pack_slot(w, PF_UP_PROD, 0, 0, Cin, Cout, k2_up_fwd_ws_bytes(Cin, Cout), ws, &need_pack);
@@ -732,7 +736,7 @@ int k2_up_fwd_launch(const float* x, const float* w, const float* bias, float* y
             if (g > 4096) g = 4096;
             k2_up_pack_weights_b3<<<(unsigned)g, 256, 0, s>>>(w, (__bf16*)wpk, Cin, Cout);
         } else {
-            const long total = (long)(Cout / 64) * 2 * (Cin / 8) * 32 * 512;
+            const long total = (long)((Cout + 63) / 64) * 2 * (Cin / 8) * 32 * 512;
             long g = cdiv(total, 256);
             if (g > 4096) g = 4096;
             k2_up_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, (float*)wpk, Cin, Cout);
@@ -1503,9 +1507,11 @@ __global__ __launch_bounds__(256) void k2_up_pack_dgrad_b3(const float* __restri
     }
 }
 
-bool k2_up_dgrad_supported(int Cin, int Cout) { return Cout % 8 == 0 && Cin % 64 == 0; }
+// Input channels (the channels of dx) in tiles of 64; a last partial tile is zero padded in the packed weights
+// and masked in the stores (fp32 kernels; the split-bf16 packing needs whole tiles).
+bool k2_up_dgrad_supported(int Cin, int Cout) { return Cout % 8 == 0 && Cin % 16 == 0; }
 size_t k2_up_dgrad_ws_bytes(int Cin, int Cout) {   // sized for the split-bf16 packing (4 KB per tap)
-    return ((size_t)(Cin / 64) * (Cout / 8) * 64 + 4) * 4096;
+    return ((size_t)((Cin + 63) / 64) * (Cout / 8) * 64 + 4) * 4096;
 }
 
 template <int LBD, int LBH, int LBW, bool SPLIT, bool BOX = false>
@@ -1524,7 +1530,7 @@ static int up_dgrad_cfg(const float* dy, const void* wp, float* dx, int N, int D
         set_error("conv3d_k3_dgrad(upsampled): cannot reserve %zu bytes of LDS", C::LDS_BYTES);
         return SIV_EHIP;
     }
-    k2_up_dgrad<LBD, LBH, LBW, SPLIT, BOX><<<dim3((unsigned)nblk, (unsigned)(Cin / 64)), 256, C::LDS_BYTES, s>>>(
+    k2_up_dgrad<LBD, LBH, LBW, SPLIT, BOX><<<dim3((unsigned)nblk, (unsigned)((Cin + 63) / 64)), 256, C::LDS_BYTES, s>>>(
         dy, wp, dx, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
     SIV_CHECK_LAUNCH("conv3d_k3_dgrad(upsampled)");
     return SIV_OK;
@@ -1536,6 +1542,7 @@ int k2_up_dgrad_launch(const float* dy, const float* w, float* dx, int N, int D,
                        int Cout, void* ws, size_t ws_bytes, hipStream_t s, bool split, bool force_box) {
     // the box form on request and from 32 K output voxels upwards (1.35x faster at the benchmark sizes);
     // tiny volumes keep the 16-tap form
+    if (Cin % 64 != 0) split = false;
     const bool box = !split && (force_box || (long)N * D * H * W >= (1L << 15));
     SIV_CHECK_WS(k2_up_dgrad_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3_dgrad(upsampled)");
     bool need_pack;
@@ -1548,12 +1555,12 @@ int k2_up_dgrad_launch(const float* dy, const float* w, float* dx, int N, int D,
             if (g > 4096) g = 4096;
             k2_up_pack_dgrad_b3<<<(unsigned)g, 256, 0, s>>>(w, (__bf16*)wpk, Cin, Cout);
         } else if (box) {
-            const long total = (long)(Cin / 64) * (Cout / 8) * 36 * 512;
+            const long total = (long)((Cin + 63) / 64) * (Cout / 8) * 36 * 512;
             long g = cdiv(total, 256);
             if (g > 4096) g = 4096;
             k2_up_pack_dgrad_box<<<(unsigned)g, 256, 0, s>>>(w, (float*)wpk, Cin, Cout);
         } else {
-            const long total = (long)(Cin / 64) * (Cout / 8) * 64 * 512;
+            const long total = (long)((Cin + 63) / 64) * (Cout / 8) * 64 * 512;
             long g = cdiv(total, 256);
             if (g > 4096) g = 4096;
             k2_up_pack_dgrad<<<(unsigned)g, 256, 0, s>>>(w, (float*)wpk, Cin, Cout);

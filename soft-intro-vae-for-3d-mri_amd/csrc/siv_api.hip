@@ -292,7 +292,7 @@ extern "C" int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bi
     if (path != 1 && al && ups == 1 && k3_thin_supported(Cin, Cout))
         return SIV_PICK("thin"), k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s, nullptr);
     if (use_up(path, al, ups, Cin, Cout))
-        return SIV_PICK("up"), k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, nullptr, path == 5, path == 6);
+        return SIV_PICK("up"), k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, nullptr, path == 5 && Cout % 64 == 0, path == 6);
     if (use_b3(path, al, ups, Cin, Cout))
         return SIV_PICK("wino_b3"), k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, nullptr);
     if (use_w2d(path, al, ups, N, D, H, W, Cin, Cout))
@@ -331,7 +331,7 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
         nblk = k3_thin_fwd_stat_blocks(N, D, H, W, Cin, Cout);
         if (nblk > 0) fused = THIN;
     } else if (use_up(path, al, ups, Cin, Cout)) {
-        fused = UP, wbytes = k2_up_fwd_ws_bytes(Cin, Cout), nblk = k2_up_fwd_blocks(N, D, H, W, path == 5, path == 6);
+        fused = UP, wbytes = k2_up_fwd_ws_bytes(Cin, Cout), nblk = k2_up_fwd_blocks(N, D, H, W, path == 5 && Cout % 64 == 0, path == 6);
     } else if (use_b3(path, al, ups, Cin, Cout)) {
         fused = B3, wbytes = k3_fwd_wino_b3_ws_bytes(Cin, Cout), nblk = k3_fwd_wino_bricks(N, D, H, W);
     } else if (use_w2d(path, al, ups, N, D, H, W, Cin, Cout)) {
@@ -346,7 +346,7 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
         SIV_PICK(fused == UP ? "up" : fused == B3 ? "wino_b3" : fused == W2D ? "wino2d" : fused == THIN ? "thin" : "wino");
         switch (fused) {
         case THIN: rc = k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s, part); break;
-        case UP: rc = k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, part, path == 5, path == 6); break;
+        case UP: rc = k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, part, path == 5 && Cout % 64 == 0, path == 6); break;
         case B3: rc = k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part); break;
         case W2D: rc = k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part); break;
         default: rc = k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s, part); break;
@@ -535,7 +535,7 @@ extern "C" int siv_conv3d_k3_dgrad_up(const float* dy, const float* w, float* dx
     SIV_CHECK_ARG(aligned16(dy) && aligned16(w) && aligned16(dx) && aligned16(ws),
                   "conv3d_k3_dgrad_up: pointers must be 16-byte aligned");
     SIV_CHECK_ARG(k2_up_dgrad_supported(Cin, Cout),
-                  "conv3d_k3_dgrad_up: needs Cin %% 64 == 0 and Cout %% 8 == 0 (got Cin=%d Cout=%d); use "
+                  "conv3d_k3_dgrad_up: needs Cin %% 16 == 0 and Cout %% 8 == 0 (got Cin=%d Cout=%d); use "
                   "siv_conv3d_k3_dgrad followed by siv_upsample2_bwd", Cin, Cout);
     SIV_PICK("up");
     return k2_up_dgrad_launch(dy, w, dx, N, D, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream, conv_path() == 5,

@@ -83,6 +83,11 @@ CONV_CASES = [
     # ... and behind an upsample (collapsed-tap weight gradient in its narrow modes; 10-wide low-resolution bricks)
     (16, 16, (8, 16, 16), 2, 2, 0), (8, 32, (12, 8, 40), 1, 2, 0), (32, 16, (8, 8, 40), 2, 2, 0),
     (16, 32, (16, 24, 40), 1, 2, 0),
+    # ... whose forward runs on the collapsed-tap / product-form kernels with a partial 64-channel output tile
+    (32, 16, (16, 24, 40), 2, 2, 0), (8, 48, (6, 10, 14), 2, 2, 0), (64, 32, (8, 8, 16), 1, 2, 6), (16, 80, (4, 24, 40), 1, 2, 5),
+    # ... and whose input gradient runs as the stride-2 convolution with a partial 64-channel tile of dx
+    # (16-tap and box forms, 10-wide bricks, a whole tile plus a partial one)
+    (16, 8, (6, 10, 14), 2, 2, 0), (32, 32, (16, 24, 40), 1, 2, 0), (80, 16, (4, 24, 40), 1, 2, 0), (48, 8, (2, 2, 2), 1, 2, 6),
     # widths 10 / 20 (the two deepest levels of an 80x96x80 input): 10-wide bricks in 3-wave blocks
     (8, 64, (10, 24, 20), 1, 1, 0), (16, 64, (10, 24, 20), 1, 2, 0), (8, 128, (5, 12, 10), 2, 1, 0),
     (64, 64, (10, 12, 10), 1, 1, 0), (8, 64, (4, 6, 10), 1, 2, 0),
@@ -468,6 +473,8 @@ def test_add_act(B, shape):
     (32, 64, (20, 24, 40), 5, 1, 6, True),
     # ... and the product form of the upsampled kernel (forced by path 6; one-plane bricks, 20-wide variant)
     (64, 128, (8, 8, 16), 1, 2, 6, True), (16, 64, (10, 24, 20), 1, 2, 6, False), (8, 64, (6, 10, 14), 2, 2, 6, True),
+    # ... with a partial output-channel tile (16, 32, 80 channels), both forms, and under the split-bf16 path
+    (32, 16, (16, 24, 40), 2, 2, 0, True), (16, 32, (8, 12, 20), 1, 2, 6, False), (16, 80, (4, 24, 40), 1, 2, 5, True),
     (4, 8, (6, 7, 5), 2, 1, 0, True), (1, 8, (8, 12, 8), 2, 1, 0, True), (64, 64, (10, 12, 10), 1, 1, 0, False),
     # ... and the single-channel stem on the matrix pipe (ragged bricks, several bricks per block, narrow widths)
     (1, 64, (9, 10, 11), 2, 1, 0, True), (1, 64, (16, 24, 40), 3, 1, 0, True), (1, 16, (7, 9, 12), 2, 1, 0, False),
