@@ -1057,6 +1057,14 @@ int k2_up_wgrad_launch(const float* x, const float* dy, float* dw, int N, int D,
 //   K       = 64 taps x Cout, walked as (8-channel chunk, u along D): each step stages the dy planes
 //             2z + u of the brick (W-parity split, so that the stride-2 reads are unit-stride in LDS)
 //             and runs the 16 (u along H, u along W) taps on them
+// SIV_UPD_LINE=0 (build flag) keeps the four-plane box kernel at every size
+#ifndef SIV_UPD_LINE
+#define SIV_UPD_LINE 1
+#endif
+
+// box form: log2 of the number of 8-channel chunks whose steps are grouped (see k2_up_dgrad)
+__host__ __device__ inline int up_dgrad_group_shift(int nchunk) { return nchunk % 4 == 0 ? 2 : nchunk % 2 == 0 ? 1 : 0; }
+
 template <int LBD_, int LBH_, int LBW_>
 struct UdCfg {
     static constexpr int LBD = LBD_, LBH = LBH_, LBW = LBW_;
@@ -1195,8 +1203,14 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
     int* const park = reinterpret_cast<int*>(lds + C::V_FLOATS + C::SLACK) + 4 * tid;
     if constexpr (BOX && C::PARK > 0)
         *reinterpret_cast<int4*>(park) = make_int4(hoff[NHR], hoff[NHR + 1], hoff[NHR + 2], hoff[NHR + 3]);
+    // BOX: the steps of up to four chunks -- the 128 bytes of a voxel that arrive as one cache line -- are taken
+    // together, step = ((group * 4 + u index) * G + chunk in group): the four steps that use a line follow each
+    // other (in the order (chunk, u) a line was fetched again sixteen steps later, by then from HBM: 8.5x the
+    // bytes of dy per launch, which bounded the kernel).
+    const int gsh = BOX ? up_dgrad_group_shift(Cout / C::CK) : 0;
     auto load_halo = [&](int step) {
-        const int c0 = (step >> 2) * C::CK, u = (step & 3) - 1;
+        const int c0 = BOX ? (((step >> (2 + gsh)) << gsh) + (step & ((1 << gsh) - 1))) * C::CK : (step >> 2) * C::CK;
+        const int u = ((step >> gsh) & 3) - 1;
         unsigned mk = 0;
         if constexpr (BOX) {
             const int delta = (u * H * W * Cout + c0) * 4;
@@ -1418,6 +1432,234 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------
+// the box form, one whole cache line per staged voxel
+// ---------------------------------------------------------------------------------
+// k2_up_dgrad<.., BOX> stages four dy planes with 8 channels per voxel and step: 32 of the 128 bytes that a
+// voxel's cache line delivers, and the line comes back for the other chunks and for the second (z, u) pair
+// that uses the plane after hundreds of kilobytes of other lines -- measured at 64 -> 64 @80x96x80: 10.2 GB
+// of 128-byte requests from the L2 to the fabric per launch for 1.26 GB of dy, 5.5 TB/s, which bounded the
+// kernel.  Here a step stages ONE plane 2 (z0 + dz) + u with 32 channels per voxel (whole lines, used once per
+// (dz, u)) and multiplies it into the row tiles of plane dz alone:
+//   M rows  = 4 x 8 x 8 low-resolution voxels; wave (wm, wn) owns row tile wm of each plane dz (4 accumulators)
+//             for the input-channel half wn
+//   K       = walked as (32-channel group, u along D, dz): 9 box taps x four 8-channel groups = 36 units of
+//             4 matrix instructions per step and wave, as many as in the four-plane form
+// Weights: the box packing in the kernel's step order (k2_up_pack_dgrad_box), whose 36 slices per (group, u)
+// are re-read for the four dz.  Staging, box sums in place and the epilogue follow the four-plane form.
+#ifndef SIV_UL_BLOCKS
+#define SIV_UL_BLOCKS 3
+#endif
+#ifndef SIV_UL_PD
+#define SIV_UL_PD 3
+#endif
+#ifndef SIV_UL_PARK
+#define SIV_UL_PARK 0
+#endif
+struct UlCfg {
+    static constexpr int LBD = 4, LBH = 8, LBW = 8;
+    static constexpr int CG = 32, CKP = 36;                 // channels per voxel and step; floats per voxel (bank spread)
+    static constexpr int NTHR = 256, NT = 64, AM = 4;
+    static constexpr int HH = 2 * LBH + 2, HWF = 2 * LBW + 2, HWH = LBW + 1;
+    static constexpr int PITCH = 656;                       // floats per halo row: >= 2 * HWH * CKP, = 16 mod 32
+    static constexpr int HV = HH * HWF;                     // dy voxels staged per step (324)
+    static constexpr int NH = (HV * 8 + NTHR - 1) / NTHR;   // 16-byte items per thread (11)
+    static constexpr int V_FLOATS = HH * PITCH;
+    static constexpr int UNITS = 36, SLICE = NT * 8;
+    static constexpr int EPI_STRIDE = 40, EPI_FLOATS = 32 * EPI_STRIDE;
+    static constexpr int SLACK = PITCH + HWH * CKP + CG;    // what the box sums of the last halo row touch behind the image
+    static constexpr int PARK = SIV_UL_PARK;                // load offsets per thread parked in LDS (0 or 4)
+    static constexpr size_t LDS_BYTES = (size_t)(V_FLOATS + SLACK + PARK * NTHR) * sizeof(float);
+    static_assert(PITCH >= 2 * HWH * CKP && PITCH % 32 == 16, "row pitch");
+    static_assert(V_FLOATS >= 4 * EPI_FLOATS, "epilogue tiles fit");
+};
+
+__global__ __launch_bounds__(256, SIV_UL_BLOCKS) void k2_up_dgrad_line(const float* __restrict__ dy,
+                                                           const float* __restrict__ wp,
+                                                           float* __restrict__ dx, int N, int D, int H, int W,
+                                                           int Cin, int Cout, int nbd, int nbh, int nbw) {
+    using C = UlCfg;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    const int bx = b % nbw; b /= nbw;
+    const int by = b % nbh; b /= nbh;
+    const int bz = b % nbd;
+    const int n = b / nbd;
+    const int z0 = bz * C::LBD, y0 = by * C::LBH, x0 = bx * C::LBW;      // low-resolution origin of the brick
+    const int ci0 = blockIdx.y * C::NT;
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
+    const int nseq = (Cout / C::CG) * 4;                        // (channel group, u along D); four steps (dz) each
+    const int nstep = nseq * 4;
+
+    // LDS offset of this lane's A row (row tile wm of the staged plane) for box (0, 0), channel group 0
+    const int mrow = wm * 32 + li;
+    const int aoff = (2 * (mrow / C::LBW)) * C::PITCH + (mrow % C::LBW) * C::CKP + 4 * lh;
+    auto unitoff = [&](int u) {      // unit u = (8-channel group kq, box tap t = e_h * 3 + p_x)
+        const int kq = u / 9, t = u % 9;
+        const int eh = t / 3, px = t % 3;
+        return eh * C::PITCH + ((px & 1) * C::HWH + (px >> 1)) * C::CKP + 8 * kq;
+    };
+
+    constexpr int PD = SIV_UL_PD;    // weight slices in flight; divides the 36 units of a step
+    static_assert(C::UNITS % PD == 0, "ring index must not depend on the step");
+    float4 bring[PD];
+    const __amdgpu_buffer_rsrc_t drs = buf_rsrc(dy + (long)n * D * H * W * Cout, (long)D * H * W * Cout * 4);
+    const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(wp, (long)gridDim.y * nseq * C::UNITS * C::SLICE * 4);
+    const unsigned wvo = ((wn * 32 + li) * 8 + 4 * lh) * 4;
+    const int wso0 = (int)blockIdx.y * nseq * C::UNITS * C::SLICE * 4;
+    constexpr unsigned UP_OUTSIDE = 0xC0000000u;
+
+    // staging: item = (voxel of the staged plane, 16-byte piece of its 32 channels).  A thread keeps its piece
+    // q and walks the 18 x 18 halo voxels in a regular pattern -- items 0..8: column v & 15 of rows 2 i + (v >> 4);
+    // items 9, 10: columns 16 and 17 of rows (v >> 1) + 16 (i - 9), v = tid >> 3 -- so that the LDS addresses of
+    // all items are two registers plus constants.  Global offsets are those of plane 2 * z0; the step adds the
+    // plane (2 dz + u) and the channel group, and a plane outside the sample lands outside the descriptor by itself.
+    static_assert(C::HH == 18 && C::HWF == 18 && C::NH == 11, "item pattern");
+    float4 hreg[C::NH];
+    int hoff[C::NH];
+    const int sv = tid >> 3, sq = tid & 7;
+    // item 10 covers rows 16 and 17 only: the other threads repeat their item 9 (same source, same destination,
+    // same box sum) instead of branching
+    const bool last_ok = tid < 32;
+    auto item_row = [&](int i) { return i < 9 ? 2 * i + (sv >> 4) : (sv >> 1) + 16 * (i - 9); };
+    const int colA = sv & 15, colB = 16 + (sv & 1);
+    const int hdstA = (sv >> 4) * C::PITCH + ((colA & 1) * C::HWH + (colA >> 1)) * C::CKP + 4 * sq;
+    const int hdstB = (sv >> 1) * C::PITCH + ((colB & 1) * C::HWH + (colB >> 1)) * C::CKP + 4 * sq;
+    const int hdstL = last_ok ? hdstB + 16 * C::PITCH : hdstB;
+    auto hdst = [&](int i) { return i < 9 ? hdstA + 2 * i * C::PITCH : i == 9 ? hdstB : hdstL; };
+    // LDS offset of the voxel to the right minus this voxel's: the column parity is that of v for every item
+    const int hnx = (sv & 1) ? (1 - C::HWH) * C::CKP : C::HWH * C::CKP;
+#pragma unroll
+    for (int i = 0; i < C::NH; ++i) {
+        const int hy = i == 10 && !last_ok ? item_row(9) : item_row(i), hx = i < 9 ? colA : colB;
+        const int gy = 2 * y0 - 1 + hy, gx = 2 * x0 - 1 + hx;
+        const bool ok = hy < C::HH && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        hoff[i] = ok ? (int)((((2 * z0 * H + gy) * W + gx) * Cout + 4 * sq) * 4) : (int)UP_OUTSIDE;
+    }
+    constexpr int NHR = C::NH - C::PARK;
+    int* const park = reinterpret_cast<int*>(lds + C::V_FLOATS + C::SLACK) + 4 * tid;
+    if constexpr (C::PARK > 0)
+        *reinterpret_cast<int4*>(park) = make_int4(hoff[NHR], hoff[NHR + 1], hoff[NHR + 2], hoff[NHR + 3]);
+    auto load_halo = [&](int step) {
+        const int dz = step & 3, u = ((step >> 2) & 3) - 1, c0 = (step >> 4) * C::CG;
+        const int delta = ((2 * dz + u) * H * W * Cout + c0) * 4;
+        int4 pk = make_int4(0, 0, 0, 0);
+        if constexpr (C::PARK > 0) pk = *reinterpret_cast<const int4*>(park);
+#pragma unroll
+        for (int i = 0; i < NHR; ++i) hreg[i] = buf_load16(drs, (unsigned)(hoff[i] + delta), 0);
+        if constexpr (C::PARK > 0) {
+            hreg[NHR + 0] = buf_load16(drs, (unsigned)(pk.x + delta), 0);
+            hreg[NHR + 1] = buf_load16(drs, (unsigned)(pk.y + delta), 0);
+            hreg[NHR + 2] = buf_load16(drs, (unsigned)(pk.z + delta), 0);
+            hreg[NHR + 3] = buf_load16(drs, (unsigned)(pk.w + delta), 0);
+        }
+    };
+    load_halo(0);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) bring[i] = buf_load16(wrs, wvo, wso0 + i * C::SLICE * 4);
+#define SIV_PIN(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
+#pragma unroll
+    for (int i = 0; i < C::NH; ++i) SIV_PIN(hreg[i]);
+#pragma unroll
+    for (int i = 0; i < PD; ++i) SIV_PIN(bring[i]);
+
+    f32x16 acc[C::AM];
+#pragma unroll
+    for (int a = 0; a < C::AM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    for (int seq = 0; seq < nseq; ++seq) {
+#pragma unroll
+        for (int dz = 0; dz < 4; ++dz) {
+            const int step = seq * 4 + dz;
+            SIV_UDS(0);
+            __syncthreads();  // previous step's matrix instructions are done with the plane
+            SIV_UDS(1);
+#pragma unroll
+            for (int i = 0; i < C::NH; ++i)
+                *reinterpret_cast<float4*>(lds + hdst(i)) = hreg[i];
+            __syncthreads();
+            SIV_UDS(2);
+            // raw image -> box image, in place: this voxel + right + below + below right (the last row and
+            // column of the halo have no box of their own; what they add up is never read)
+#pragma unroll
+            for (int i = 0; i < C::NH; ++i) {
+                const float* d = lds + hdst(i);
+                const float4 r1 = *reinterpret_cast<const float4*>(d + hnx);
+                const float4 r2 = *reinterpret_cast<const float4*>(d + C::PITCH);
+                const float4 r3 = *reinterpret_cast<const float4*>(d + C::PITCH + hnx);
+                hreg[i].x = (hreg[i].x + r1.x) + (r2.x + r3.x);
+                hreg[i].y = (hreg[i].y + r1.y) + (r2.y + r3.y);
+                hreg[i].z = (hreg[i].z + r1.z) + (r2.z + r3.z);
+                hreg[i].w = (hreg[i].w + r1.w) + (r2.w + r3.w);
+                // the sums are formed here, not where they are stored: three items' reads in flight, not all
+                if (SIV_UL_BLOCKS > 2 && i >= 2) SIV_PIN(hreg[i - 2]);
+                if (i % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            SIV_UDS(3);
+            __syncthreads();  // every neighbour has been read
+            SIV_UDS(4);
+#pragma unroll
+            for (int i = 0; i < C::NH; ++i)
+                *reinterpret_cast<float4*>(lds + hdst(i)) = hreg[i];
+            __syncthreads();
+            SIV_UDS(5);
+            load_halo(step + 1 < nstep ? step + 1 : step);
+            SIV_UDS(6);
+
+            // the 36 slices of this (group, u); the ring runs on into the next step's (the same ones for dz < 3)
+            const int wcur = wso0 + seq * C::UNITS * C::SLICE * 4;
+            const int wnxt = dz < 3 ? wcur : wcur + C::UNITS * C::SLICE * 4;
+            float4 av = *reinterpret_cast<const float4*>(lds + aoff + unitoff(0));
+#pragma unroll
+            for (int u = 0; u < C::UNITS; ++u) {
+                const float4 bv = bring[u % PD];
+                bring[u % PD] = u + PD < C::UNITS ? buf_load16(wrs, wvo, wcur + (u + PD) * C::SLICE * 4)
+                                                  : buf_load16(wrs, wvo, wnxt + (u + PD - C::UNITS) * C::SLICE * 4);
+                const float4 a4 = av;
+                if (u + 1 < C::UNITS) av = *reinterpret_cast<const float4*>(lds + aoff + unitoff(u + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                acc[dz] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bv.x, acc[dz], 0, 0, 0);
+                acc[dz] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bv.y, acc[dz], 0, 0, 0);
+                acc[dz] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bv.z, acc[dz], 0, 0, 0);
+                acc[dz] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bv.w, acc[dz], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            SIV_UDS(7);
+        }
+    }
+
+    // store: transpose each 32x32 tile through this wave's slice of LDS, write 16-byte channel runs
+    float* tile = lds + wave * C::EPI_FLOATS;
+    const int cq = lane & 7;
+    const int ci = ci0 + wn * 32 + 4 * cq;
+#pragma unroll
+    for (int a = 0; a < C::AM; ++a) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * C::EPI_STRIDE + li] = acc[a][r];
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = ps * 8 + (lane >> 3);
+            const int pm = wm * 32 + row;                       // voxel of plane a
+            const int gz = z0 + a, gy = y0 + pm / C::LBW, gx = x0 + pm % C::LBW;
+            const float4 v = *reinterpret_cast<const float4*>(tile + row * C::EPI_STRIDE + 4 * cq);
+            if (gz < Dl && gy < Hl && gx < Wl && ci < Cin)
+                *reinterpret_cast<float4*>(dx + ((((long)n * Dl + gz) * Hl + gy) * Wl + gx) * Cin + ci) = v;
+        }
+    }
+}
+#undef SIV_PIN
+
 // Packed 4x4x4 stride-2 kernel: wp[ct][cc][ud][t = (uh, uw)][ci (64)][co (8)] from w[Kout][27][Kin];
 // along an axis, offset u = -1, 0, 1, 2 (index 0..3) sums the original taps {2}, {1,2}, {0,1}, {0}.
 __global__ __launch_bounds__(256) void k2_up_pack_dgrad(const float* __restrict__ w, float* __restrict__ wp,
@@ -1449,8 +1691,9 @@ __global__ __launch_bounds__(256) void k2_up_pack_dgrad(const float* __restrict_
     }
 }
 
-// The box form: wp[ct][cc][ud][t = e_h * 3 + e_w][ci (64)][co (8)] = sum over the taps kd that collapse
-// onto ud of w[co][kd][2 - e_h][2 - e_w][ci] (the box that starts e rows below 2j - 1 belongs to tap 2 - e).
+// The box form: wp[ct][step][t = e_h * 3 + e_w][ci (64)][co (8)] = sum over the taps kd that collapse
+// onto ud of w[co][kd][2 - e_h][2 - e_w][ci] (the box that starts e rows below 2j - 1 belongs to tap 2 - e),
+// the steps in the kernel's order: ((chunk group * 4 + ud) * G + chunk in group), G = 1 << up_dgrad_group_shift.
 __global__ __launch_bounds__(256) void k2_up_pack_dgrad_box(const float* __restrict__ w, float* __restrict__ wp,
                                                             int Kin, int Kout) {
     const int nchunk = Kout / 8, ntile = (Kin + 63) / 64;
@@ -1461,9 +1704,11 @@ __global__ __launch_bounds__(256) void k2_up_pack_dgrad_box(const float* __restr
         long r = i >> 3;
         const int ci = (int)(r & 63); r >>= 6;
         const int t = (int)(r % 9); r /= 9;
-        const int ud = (int)(r & 3); r >>= 2;
-        const int cc = (int)(r % nchunk);
-        const int ct = (int)(r / nchunk);
+        const int step = (int)(r % (nchunk * 4));
+        const int ct = (int)(r / (nchunk * 4));
+        const int gsh = up_dgrad_group_shift(nchunk);
+        const int ud = (step >> gsh) & 3;
+        const int cc = ((step >> (2 + gsh)) << gsh) + (step & ((1 << gsh) - 1));
         const int kh = 2 - t / 3, kw = 2 - t % 3;
         const int kci = ct * 64 + ci, kco = cc * 8 + j;
         float v = 0.f;
@@ -1573,6 +1818,26 @@ int k2_up_dgrad_launch(const float* dy, const float* w, float* dx, int N, int D,
     }
     if (box) {
         if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, false, true>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);
+        // whole cache lines per staged voxel where the channel groups are whole (32) and the lane offsets,
+        // shifted by up to nine planes, stay clear of the marker for voxels outside the sample
+        if (SIV_UPD_LINE && Cout % 32 == 0 && (long)(D + 10) * H * W * Cout * 4 < (1L << 30)) {
+            using C = UlCfg;
+            const int nbd = (int)cdiv(D / 2, C::LBD), nbh = (int)cdiv(H / 2, C::LBH), nbw = (int)cdiv(W / 2, C::LBW);
+            const long nblk = (long)N * nbd * nbh * nbw;
+            if (nblk > 0x7fffffffL) {
+                set_error("conv3d_k3_dgrad(upsampled): too many bricks");
+                return SIV_EINVAL;
+            }
+            if (hipFuncSetAttribute((const void*)k2_up_dgrad_line, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)C::LDS_BYTES) != hipSuccess) {
+                set_error("conv3d_k3_dgrad(upsampled): cannot reserve %zu bytes of LDS", C::LDS_BYTES);
+                return SIV_EHIP;
+            }
+            k2_up_dgrad_line<<<dim3((unsigned)nblk, (unsigned)((Cin + 63) / 64)), 256, C::LDS_BYTES, s>>>(
+                dy, (const float*)wpk, dx, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
+            SIV_CHECK_LAUNCH("conv3d_k3_dgrad(upsampled, whole lines)");
+            return SIV_OK;
+        }
         return up_dgrad_cfg<4, 8, 8, false, true>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);
     }
     if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, false>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);

@@ -130,6 +130,11 @@ CONV_CASES = [
     # output-channel tiles (144 bricks x 2 on 128 x 2 blocks); forward and input gradient
     (32, 64, (20, 24, 40), 5, 1, 6), (64, 64, (12, 24, 40), 7, 1, 6), (64, 64, (12, 24, 20), 11, 1, 6),
     (64, 128, (16, 24, 24), 4, 1, 6),
+    # box-form input gradient behind an upsample with a whole cache line (32 channels) per staged voxel
+    # (Cout % 32 == 0, low-resolution width not a multiple of 10): three channel groups with a whole and a
+    # partial 64-channel tile of dx and partial bricks along every axis; several whole bricks per sample on
+    # the automatic path; one channel group
+    (80, 96, (12, 20, 18), 2, 2, 6), (64, 64, (16, 32, 32), 2, 2, 0), (16, 32, (10, 16, 16), 1, 2, 6),
     # the same wide shapes through the generic kernels (cross-check of the dispatcher)
     (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
 ]
