@@ -1447,6 +1447,16 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
 //             4 matrix instructions per step and wave, as many as in the four-plane form
 // Weights: the box packing in the kernel's step order (k2_up_pack_dgrad_box), whose 36 slices per (group, u)
 // are re-read for the four dz.  Staging, box sums in place and the epilogue follow the four-plane form.
+// SIV_UL_EXP: timing-only ablation mask (never set in the library build; results are wrong with it):
+// 1 = no weight loads in the multiply loop, 2 = no dy loads, 4 = no box phase (neighbour reads, sums, two
+// barriers).  Measured at 64 -> 64 @80x96x80, batch 8: full 1.69 ms, 1: 1.63, 2: 1.59, 4: 1.54, all three
+// 1.35 (the matrix instructions alone: 1.15 ms; 2400 blocks on 768 slots leave a last round an eighth full).
+#ifndef SIV_UL_EXP
+#define SIV_UL_EXP 0
+#endif
+// SIV_UL_BLOCKS blocks per CU (3: 168 registers, no parked offsets, sums pinned where they are formed),
+// SIV_UL_PD weight slices in flight (divides 36), SIV_UL_PARK load offsets kept in LDS (0 or 4).
+// Measured (blocks, slices, parked): (2, 4, 4) 1.68 ms, (2, 6, 4) 1.69, (2, 9, 4) 1.69, (3, 3, 0) 1.65.
 #ifndef SIV_UL_BLOCKS
 #define SIV_UL_BLOCKS 3
 #endif
@@ -1588,6 +1598,7 @@ __global__ __launch_bounds__(256, SIV_UL_BLOCKS) void k2_up_dgrad_line(const flo
                 *reinterpret_cast<float4*>(lds + hdst(i)) = hreg[i];
             __syncthreads();
             SIV_UDS(2);
+            if (!(SIV_UL_EXP & 4)) {
             // raw image -> box image, in place: this voxel + right + below + below right (the last row and
             // column of the halo have no box of their own; what they add up is never read)
 #pragma unroll
@@ -1611,8 +1622,9 @@ __global__ __launch_bounds__(256, SIV_UL_BLOCKS) void k2_up_dgrad_line(const flo
             for (int i = 0; i < C::NH; ++i)
                 *reinterpret_cast<float4*>(lds + hdst(i)) = hreg[i];
             __syncthreads();
+            }
             SIV_UDS(5);
-            load_halo(step + 1 < nstep ? step + 1 : step);
+            if (!(SIV_UL_EXP & 2)) load_halo(step + 1 < nstep ? step + 1 : step);
             SIV_UDS(6);
 
             // the 36 slices of this (group, u); the ring runs on into the next step's (the same ones for dz < 3)
@@ -1622,6 +1634,7 @@ __global__ __launch_bounds__(256, SIV_UL_BLOCKS) void k2_up_dgrad_line(const flo
 #pragma unroll
             for (int u = 0; u < C::UNITS; ++u) {
                 const float4 bv = bring[u % PD];
+                if (!(SIV_UL_EXP & 1))
                 bring[u % PD] = u + PD < C::UNITS ? buf_load16(wrs, wvo, wcur + (u + PD) * C::SLICE * 4)
                                                   : buf_load16(wrs, wvo, wnxt + (u + PD - C::UNITS) * C::SLICE * 4);
                 const float4 a4 = av;
