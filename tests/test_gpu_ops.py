@@ -246,7 +246,10 @@ def test_upsample2_bwd(B):
 
 
 @pytest.mark.parametrize("c,dims,n", [(4, (6, 7, 5), 3), (64, (8, 12, 8), 2), (12, (4, 4, 4), 1),
-                                      (256, (2, 3, 2), 3), (1, (5, 5, 5), 2), (300, (2, 2, 2), 2)])
+                                      (256, (2, 3, 2), 3), (1, (5, 5, 5), 2), (300, (2, 2, 2), 2),
+                                      # more than 1024 rows of per-block partial sums: folded onto 256 rows first
+                                      # (1152 rows of 6 columns; 1040 rows of 16 columns through the 16-byte kernels)
+                                      (3, (32, 48, 48), 1), (8, (64, 130, 128), 1)])
 def test_bn_stats(B, c, dims, n):
     gen = torch.Generator().manual_seed(c)
     y = rnd(gen, n, c, *dims) * (1 + torch.arange(c).view(1, c, 1, 1, 1) % 5) + \
@@ -270,6 +273,8 @@ BN_CASES = [  # c, dims, n, slope, pool, residual, dropout p
     (8, (4, 6, 4), 2, 0.2, 1, True, 0.0), (8, (4, 6, 4), 2, 0.0, 1, True, 0.0),
     (64, (8, 12, 8), 2, 0.2, 1, False, 0.35), (64, (8, 12, 8), 1, 0.2, 2, False, 0.0),
     (12, (4, 4, 4), 2, 0.0, 2, False, 0.0), (256, (2, 3, 2), 3, 0.2, 1, True, 0.25),
+    # more than 1024 rows of per-block backward sums (folded onto 256 rows before the per-channel kernel)
+    (8, (64, 130, 128), 1, 0.2, 1, False, 0.0), (3, (32, 48, 48), 1, 0.2, 1, True, 0.0),
 ]
 
 
