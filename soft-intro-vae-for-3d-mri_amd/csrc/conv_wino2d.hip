@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ y, int N, int D, int H, int W,
                                                         int Cin, int Cout, int nbd, int nbh, int nbw,
-                                                        int nbricks, float* __restrict__ stat_part) {
+                                                        int nbricks, float* __restrict__ stat_part, int kshift) {
     using C = W2Cfg;
     constexpr int tpr = TPR, trows = 16 / TPR;
     constexpr int BHP = 2 * trows + 2, BWP = 2 * TPR + 2;      // halo plane: 10 x 10 or 8 x 12 voxels
@@ -118,18 +118,44 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     SIV_STAMP(0);
 
     // brick of a dispatch index: each XCD (index mod 8) walks a contiguous eighth of the bricks
+    // (kshift > 0: an item is (brick, quarter of the input channels) and the block chooses its items itself,
+    // below; see the launcher)
+    auto item_of = [&](int b) { return !kshift && (nbricks & 7) == 0 ? (b & 7) * (nbricks >> 3) + (b >> 3) : b; };
     auto brick_of = [&](int b, int& bn, int& bz0, int& by0, int& bx0) {
-        if ((nbricks & 7) == 0) b = (b & 7) * (nbricks >> 3) + (b >> 3);
+        b = item_of(b) >> kshift;
         const int bx = b % nbw; b /= nbw;
         const int by = b % nbh; b /= nbh;
         bz0 = (b % nbd) * C::BD; by0 = by * 2 * trows; bx0 = bx * 2 * tpr;
         bn = b / nbd;
     };
-    int vb = blockIdx.x;
+    int vb = blockIdx.x, cot = blockIdx.y;
+    // Channel contraction split (kshift = 2): item v = brick * 4 + part; a block's items vb, vb + gridDim.x, ...
+    // all take the same part of the input channels (gridDim.x is a multiple of 4) and leave a bias-free partial
+    // output in slab kpart of y, which is then a buffer of four outputs.  The 256 blocks of the launch are
+    // dealt out so that an XCD (dispatch index mod 8) works on ONE output-channel tile and as few parts as
+    // possible: the transformed weights of the layer (12.6 MB at 256 -> 256) do not fit an XCD's L2, the
+    // 1.6 MB of one tile and two parts do.
+    if (kshift) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, j = lin >> 3;     // j: 0..31
+        const int P = 8 / (int)gridDim.y, xc = xcd % P;        // XCDs per output-channel tile (8, 4, 2 or 1)
+        cot = xcd / P;
+        int kp, slot;
+        if (P >= 4) kp = xc & 3, slot = (xc >> 2) * 32 + j;
+        else if (P == 2) kp = (xc << 1) | (j & 1), slot = j >> 1;
+        else kp = j & 3, slot = j >> 2;
+        vb = slot * 4 + kp;
+    }
     int n, z0, y0, x0;
     brick_of(vb, n, z0, y0, x0);
-    const int co0 = blockIdx.y * C::NT;
-    const int nchunk = Cin / C::CK;
+    const int co0 = cot * C::NT;
+    const int kpart = vb & ((1 << kshift) - 1);
+    const int nchunk = (Cin / C::CK) >> kshift;                // chunks of an item
+    const int kc0 = kpart * nchunk * C::CK;                    // its first input channel
+    if (kshift) {
+        y += (long)kpart * N * D * H * W * Cout;
+        bias = nullptr;
+        stat_part = nullptr;
+    }
 
     // A row m = a*32 + li is tile (dz = m >> 4, th, tw) and reads V row (dz + kd)*16 + tile = m + 16*kd.
     // A V row holds the 8 channels of a chunk without padding; the two 16-byte halves of the rows of an odd
@@ -141,9 +167,9 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     // Every vector instruction beside the fp32 matrix instructions costs matrix-pipe time (the two do not
     // overlap on a SIMD), so the loop addresses global memory through buffer descriptors: per-lane offsets
     // stay constant and everything that moves is scalar.
-    const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(wp, ((long)gridDim.y * nchunk + 1) * C::TAPS * C::SLICE * 4);
+    const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(wp, ((long)gridDim.y * (Cin / C::CK) + 1) * C::TAPS * C::SLICE * 4);
     const unsigned wvo = ((ph * 4) * C::SLICE + (wn * 32 + li) * 8 + 4 * lh) * 4;
-    const int wso0 = (int)blockIdx.y * nchunk * C::TAPS * C::SLICE * 4;
+    const int wso0 = (cot * (Cin / C::CK) + kpart * nchunk) * C::TAPS * C::SLICE * 4;
     constexpr int PD = C::PD;
     float4 bring[PD];
 
@@ -152,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
     // items per chunk with plain coalesced loads (pairs of lanes read 32 contiguous bytes) two chunks ahead
     // and stores them ten taps later; the overlapping 4x4 patches are then cut out of LDS.
     const long sample = (long)D * H * W * Cin;
-    __amdgpu_buffer_rsrc_t xrs = buf_rsrc(x + n * sample, sample * 4);       // sample of the brick being fetched
+    __amdgpu_buffer_rsrc_t xrs = buf_rsrc(x + n * sample + kc0, (sample - kc0) * 4);   // sample of the brick being fetched
     unsigned roff[3];
     // (`opaque`: a copy of tid the compiler cannot see through, so that what depends only on the lane is
     // recomputed where it is used -- once per brick -- instead of living in registers through the chunk loop,
@@ -325,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
                 if (t == 10) store_raw(rnxt);
                 if (t == 11 && has_next && cc + 3 == nchunk) {
                     halo_offsets(nz0, ny0, nx0);
-                    xrs = buf_rsrc(x + nn * sample, sample * 4);
+                    xrs = buf_rsrc(x + nn * sample + kc0, (sample - kc0) * 4);
                 }
                 // next chunk of the stream: patch reads one tap ahead of the first piece, two pieces per tap
                 if (more && s_on) {
@@ -484,9 +510,73 @@ long k3_fwd_wino2d_bricks(int N, int D, int H, int W) {
     return (long)N * cdiv(D, 4) * cdiv(H, 2 * (16 / tpr)) * cdiv(W, 2 * tpr);
 }
 // Same contract as k3_fwd_wino_launch with ups == 1 (stat_part rows: k3_fwd_wino2d_bricks()).
+// ---- channel contraction split four ways ------------------------------------------------------------
+// A level with fewer (brick, output-channel tile) units than CUs runs one round of blocks that each walk all
+// of Cin: 256 -> 256 @10x12x10, batch 8 = 192 blocks of 32 chunks on 256 CUs, 0.20 ms at 44 % of the peak.
+// Cut into quarters of the input channels the same work is 768 items = three per CU as one chunk stream
+// (24 chunks instead of 32 per block); each item leaves a partial output in a buffer of four, and
+// w2d_ksum_k adds them in a fixed order, adds the bias and forms the BatchNorm sums of its rows.
+constexpr int W2_KPARTS = 4, W2_KSUM_BLOCKS = 256;
+#ifndef SIV_W2KSPLIT
+#define SIV_W2KSPLIT 1
+#endif
+static bool w2d_ksplit(long nbricks, int Cin, int Cout) {
+    const int nchunk = Cin / 8, ncot = Cout / 64;
+    const long g = (W2_CUS / ncot) & ~7L;
+    return SIV_W2KSPLIT && W2_CHAIN && nchunk % 8 == 0 && nchunk >= 16     // items of >= 4 chunks, an even number
+        && nbricks * ncot * 5 < W2_CUS * 4                                  // one under-filled round today
+        && (ncot == 1 || ncot == 2 || ncot == 4 || ncot == 8)              // 256 blocks, whole XCDs per output tile
+        && g < nbricks * W2_KPARTS                                         // chained
+        && 256 % (Cout / 4) == 0;                                          // w2d_ksum_k's thread layout
+}
+// part: [4][M][Cout] -> y = bias + part[0] + part[1] + part[2] + part[3]; stat_part (optional): row blockIdx.x
+// = per-channel sum and sum of squares of the bias-free output over the block's voxels.
+__global__ __launch_bounds__(256) void w2d_ksum_k(const float* __restrict__ part, const float* __restrict__ bias,
+                                                  float* __restrict__ y, long M, int Cout,
+                                                  float* __restrict__ stat_part) {
+    __shared__ float4 red[2][256];
+    const int Q = Cout >> 2, vpp = 256 / Q;                    // channel quads per voxel, voxels per pass
+    const int q = threadIdx.x % Q, sub = threadIdx.x / Q;
+    const long per = (M + gridDim.x - 1) / gridDim.x;
+    const long v0 = blockIdx.x * per, v1 = v0 + per < M ? v0 + per : M;
+    const long slab = M * Cout;
+    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bq = *reinterpret_cast<const float4*>(bias + 4 * q);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long v = v0 + sub; v < v1; v += vpp) {
+        const float* p = part + v * Cout + 4 * q;
+        const float4 a0 = *reinterpret_cast<const float4*>(p), a1 = *reinterpret_cast<const float4*>(p + slab);
+        const float4 a2 = *reinterpret_cast<const float4*>(p + 2 * slab), a3 = *reinterpret_cast<const float4*>(p + 3 * slab);
+        const float4 a = w2add(w2add(a0, a1), w2add(a2, a3));
+        s1 = w2add(s1, a);
+        s2.x = fmaf(a.x, a.x, s2.x); s2.y = fmaf(a.y, a.y, s2.y); s2.z = fmaf(a.z, a.z, s2.z); s2.w = fmaf(a.w, a.w, s2.w);
+        *reinterpret_cast<float4*>(y + v * Cout + 4 * q) = w2add(a, bq);
+    }
+    if (!stat_part) return;
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < Q) {
+        float4 t1 = red[0][q], t2 = red[1][q];
+        for (int j = 1; j < vpp; ++j) { t1 = w2add(t1, red[0][j * Q + q]); t2 = w2add(t2, red[1][j * Q + q]); }
+        *reinterpret_cast<float4*>(stat_part + ((long)blockIdx.x * 2 + 0) * Cout + 4 * q) = t1;
+        *reinterpret_cast<float4*>(stat_part + ((long)blockIdx.x * 2 + 1) * Cout + 4 * q) = t2;
+    }
+}
+// Rows of BatchNorm partial sums the launch writes, and the bytes it wants behind the packed weights and those
+// rows for the four partial outputs (0: the contraction is not split for this shape).
+long k3_fwd_wino2d_stat_rows(int N, int D, int H, int W, int Cin, int Cout) {
+    const long nb = k3_fwd_wino2d_bricks(N, D, H, W);
+    return w2d_ksplit(nb, Cin, Cout) ? W2_KSUM_BLOCKS : nb;
+}
+size_t k3_fwd_wino2d_ksplit_bytes(int N, int D, int H, int W, int Cin, int Cout) {
+    return w2d_ksplit(k3_fwd_wino2d_bricks(N, D, H, W), Cin, Cout) ? (size_t)W2_KPARTS * N * D * H * W * Cout * sizeof(float) : 0;
+}
+
+// kws / kws_bytes: room for the four partial outputs of the split contraction (NULL / too small: not split).
 int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, float* y, int N, int D, int H,
                          int W, int Cin, int Cout, int flip, void* ws, size_t ws_bytes, hipStream_t s,
-                         float* stat_part) {
+                         float* stat_part, void* kws, size_t kws_bytes) {
     SIV_CHECK_WS(k3_fwd_wino2d_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(winograd 2-D)");
     SIV_CHECK_ARG((long)D * H * W * Cin < (1L << 29), "conv3d_k3(winograd 2-D): sample too large for 32-bit byte offsets");
     const long total = (long)(Cout / 64) * (Cin / 8) * 48 * 512;
@@ -514,6 +604,13 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
         long g = (W2_CUS / ncot) & ~7L;
         if (g >= 8 && g < nbricks) nblk = g;
     }
+    const size_t kneed = k3_fwd_wino2d_ksplit_bytes(N, D, H, W, Cin, Cout);
+    const bool ksplit = kneed > 0 && kws != nullptr && kws_bytes >= kneed && (((uintptr_t)kws) & 15) == 0;
+    long nitems = nbricks;
+    if (ksplit) {
+        nitems = nbricks * W2_KPARTS;
+        nblk = (W2_CUS / ncot) & ~7L;
+    }
     auto kern = tpr == 5 ? k3_fwd_wino2d<5, SIV_W2ROUNDS> : k3_fwd_wino2d<4, SIV_W2ROUNDS>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)W2Cfg::LDS_BYTES) != hipSuccess) {
@@ -521,8 +618,13 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
         return SIV_EHIP;
     }
     kern<<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 512, W2Cfg::LDS_BYTES, s>>>(
-        x, wpk, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, (int)nbricks, stat_part);
+        x, wpk, bias, ksplit ? (float*)kws : y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, (int)nitems, stat_part,
+        ksplit ? 2 : 0);
     SIV_CHECK_LAUNCH("conv3d_k3(winograd 2-D)");
+    if (ksplit) {
+        w2d_ksum_k<<<W2_KSUM_BLOCKS, 256, 0, s>>>((const float*)kws, bias, y, (long)N * D * H * W, Cout, stat_part);
+        SIV_CHECK_LAUNCH("conv3d_k3(winograd 2-D, sum of the channel parts)");
+    }
     return SIV_OK;
 }
 

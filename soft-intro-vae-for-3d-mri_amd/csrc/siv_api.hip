@@ -110,7 +110,9 @@ bool k3_fwd_wino2d_supported(int Cin, int Cout);
 size_t k3_fwd_wino2d_ws_bytes(int Cin, int Cout);
 long k3_fwd_wino2d_bricks(int N, int D, int H, int W);
 int k3_fwd_wino2d_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int, int,
-                         void*, size_t, hipStream_t, float*);
+                         void*, size_t, hipStream_t, float*, void*, size_t);
+long k3_fwd_wino2d_stat_rows(int N, int D, int H, int W, int Cin, int Cout);
+size_t k3_fwd_wino2d_ksplit_bytes(int N, int D, int H, int W, int Cin, int Cout);
 // conv_wgrad_wino.hip
 bool k3_wgrad_wino2d_supported(int Cin, int Cout);
 int k3_wgrad_wino2d_launch(const float*, const float*, float*, int, int, int, int, int, int, int, void*, size_t,
@@ -296,7 +298,9 @@ extern "C" int siv_conv3d_k3_fwd(const float* x, const float* w, const float* bi
     if (use_b3(path, al, ups, Cin, Cout))
         return SIV_PICK("wino_b3"), k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, nullptr);
     if (use_w2d(path, al, ups, N, D, H, W, Cin, Cout))
-        return SIV_PICK("wino2d"), k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, nullptr);
+        return SIV_PICK("wino2d"), k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, nullptr,
+                                                        ws_tail(ws, ws_bytes, k3_fwd_wino2d_ws_bytes(Cin, Cout)),
+                                                        ws_tail_bytes(ws_bytes, k3_fwd_wino2d_ws_bytes(Cin, Cout)));
     if (use_wino(path, al, N, D, H, W, Cin, Cout))
         return SIV_PICK("wino"), k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s, nullptr);
     if (path != 1 && al && k3_fwd_mfma_supported(Cin, Cout))
@@ -335,7 +339,7 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
     } else if (use_b3(path, al, ups, Cin, Cout)) {
         fused = B3, wbytes = k3_fwd_wino_b3_ws_bytes(Cin, Cout), nblk = k3_fwd_wino_bricks(N, D, H, W);
     } else if (use_w2d(path, al, ups, N, D, H, W, Cin, Cout)) {
-        fused = W2D, wbytes = k3_fwd_wino2d_ws_bytes(Cin, Cout), nblk = k3_fwd_wino2d_bricks(N, D, H, W);
+        fused = W2D, wbytes = k3_fwd_wino2d_ws_bytes(Cin, Cout), nblk = k3_fwd_wino2d_stat_rows(N, D, H, W, Cin, Cout);
     } else if (use_wino(path, al, N, D, H, W, Cin, Cout)) {
         fused = WINO, wbytes = k3_fwd_wino_ws_bytes(Cin, Cout), nblk = k3_fwd_wino_bricks(N, D, H, W);
     }
@@ -348,7 +352,19 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
         case THIN: rc = k3_thin_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, s, part); break;
         case UP: rc = k2_up_fwd_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ws, ws_bytes, s, part, path == 5 && Cout % 64 == 0, path == 6); break;
         case B3: rc = k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part); break;
-        case W2D: rc = k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part); break;
+        case W2D: {
+            // the partial outputs of a split channel contraction go behind the statistics rows; a workspace
+            // without room for them (the rows are then those of the unsplit launch, no more than 256) runs unsplit
+            const size_t used = wbytes + (size_t)nblk * 2 * Cout * sizeof(float);
+            void* kws = ws_tail(ws, ws_bytes, used);
+            size_t kbytes = ws_tail_bytes(ws_bytes, used);
+            if (kbytes < k3_fwd_wino2d_ksplit_bytes(N, D, H, W, Cin, Cout)) {
+                kws = nullptr, kbytes = 0;
+                nblk = k3_fwd_wino2d_bricks(N, D, H, W);
+            }
+            rc = k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part, kws, kbytes);
+            break;
+        }
         default: rc = k3_fwd_wino_launch(x, w, bias, y, N, D, H, W, Cin, Cout, ups, 0, ws, ws_bytes, s, part); break;
         }
         if (rc) return rc;
@@ -469,7 +485,9 @@ static int dgrad_dispatch(const char* what, const float* dy, const float* w, con
     if (use_b3(path, al, 1, Cout, Cin))
         return SIV_PICK("wino_b3"), k3_fwd_wino_b3_launch(dy, w, bias, dx, N, D, H, W, Cout, Cin, 1, ws, ws_bytes, s, nullptr);
     if (use_w2d(path, al, 1, N, D, H, W, Cout, Cin))
-        return SIV_PICK("wino2d"), k3_fwd_wino2d_launch(dy, w, bias, dx, N, D, H, W, Cout, Cin, 1, ws, ws_bytes, s, nullptr);
+        return SIV_PICK("wino2d"), k3_fwd_wino2d_launch(dy, w, bias, dx, N, D, H, W, Cout, Cin, 1, ws, ws_bytes, s, nullptr,
+                                                        ws_tail(ws, ws_bytes, k3_fwd_wino2d_ws_bytes(Cout, Cin)),
+                                                        ws_tail_bytes(ws_bytes, k3_fwd_wino2d_ws_bytes(Cout, Cin)));
     if (use_wino(path, al, N, D, H, W, Cout, Cin))
         return SIV_PICK("wino"), k3_fwd_wino_launch(dy, w, bias, dx, N, D, H, W, Cout, Cin, 1, 1, ws, ws_bytes, s, nullptr);
     if (path != 1 && al && k3_fwd_mfma_supported(Cout, Cin))

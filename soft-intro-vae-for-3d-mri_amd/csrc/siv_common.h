@@ -97,6 +97,15 @@ struct BnPrologue {
 
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+// what is left of a workspace behind its first `used` bytes (256-byte aligned; NULL / 0 if nothing is)
+static inline void* ws_tail(void* ws, size_t ws_bytes, size_t used) {
+    used = align256(used);
+    return used < ws_bytes ? (void*)((char*)ws + used) : nullptr;
+}
+static inline size_t ws_tail_bytes(size_t ws_bytes, size_t used) {
+    used = align256(used);
+    return used < ws_bytes ? ws_bytes - used : 0;
+}
 
 // wave64 reductions
 __device__ __forceinline__ float wave_sum(float v) {

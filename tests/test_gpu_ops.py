@@ -135,6 +135,10 @@ CONV_CASES = [
     # partial 64-channel tile of dx and partial bricks along every axis; several whole bricks per sample on
     # the automatic path; one channel group
     (80, 96, (12, 20, 18), 2, 2, 6), (64, 64, (16, 32, 32), 2, 2, 0), (16, 32, (10, 16, 16), 1, 2, 6),
+    # fewer (brick, output tile) units than CUs: the 2-D Winograd kernel splits the input channels four ways
+    # (768 / 384 items chained three per block) and a second kernel adds the partial outputs; forward and
+    # input gradient, four and two output-channel tiles, 16 and 32 chunks
+    (128, 256, (10, 12, 10), 8, 1, 6), (256, 128, (10, 12, 10), 8, 1, 0),
     # the same wide shapes through the generic kernels (cross-check of the dispatcher)
     (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
 ]
@@ -481,6 +485,8 @@ def test_add_act(B, shape):
     (64, 64, (8, 12, 8), 2, 1, 6, False), (8, 64, (5, 7, 9), 3, 1, 6, True), (16, 128, (10, 24, 20), 1, 1, 6, True),
     # ... from chained bricks (375 bricks on 256 blocks: a block emits the rows of all its bricks)
     (32, 64, (20, 24, 40), 5, 1, 6, True),
+    # ... and from the kernel that adds the four partial outputs of a split channel contraction
+    (256, 256, (10, 12, 10), 8, 1, 0, True), (128, 128, (10, 12, 10), 8, 1, 6, False),
     # ... and the product form of the upsampled kernel (forced by path 6; one-plane bricks, 20-wide variant)
     (64, 128, (8, 8, 16), 1, 2, 6, True), (16, 64, (10, 24, 20), 1, 2, 6, False), (8, 64, (6, 10, 14), 2, 2, 6, True),
     # ... with a partial output-channel tile (16, 32, 80 channels), both forms, and under the split-bf16 path

@@ -22,9 +22,9 @@ int main() {
     hipMalloc(&x, n * 4); hipMalloc(&y, n * 4); hipMalloc(&w, 64 * 27 * 64 * 4); hipMalloc(&ws, 64 << 20);
     fill<<<4096, 256>>>(x, n, 1); fill<<<64, 256>>>(w, 64 * 27 * 64, 2);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) siv::k3_fwd_wino2d_launch(x, w, nullptr, y, N, D, H, W, C, C, 0, ws, 64 << 20, 0, nullptr);
+    for (int i = 0; i < 3; ++i) siv::k3_fwd_wino2d_launch(x, w, nullptr, y, N, D, H, W, C, C, 0, ws, 64 << 20, 0, nullptr, nullptr, 0);
     hipEventRecord(e0);
-    for (int i = 0; i < 3; ++i) siv::k3_fwd_wino2d_launch(x, w, nullptr, y, N, D, H, W, C, C, 0, ws, 64 << 20, 0, nullptr);
+    for (int i = 0; i < 3; ++i) siv::k3_fwd_wino2d_launch(x, w, nullptr, y, N, D, H, W, C, C, 0, ws, 64 << 20, 0, nullptr, nullptr, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
     printf("%.3f ms per launch (with stamps)\n", ms);
