@@ -129,21 +129,21 @@ __global__ __launch_bounds__(512, 2) void k3_fwd_wino2d(const float* __restrict_
         bn = b / nbd;
     };
     int vb = blockIdx.x, cot = blockIdx.y;
-    // Channel contraction split (kshift = 2): item v = brick * 4 + part; a block's items vb, vb + gridDim.x, ...
-    // all take the same part of the input channels (gridDim.x is a multiple of 4) and leave a bias-free partial
-    // output in slab kpart of y, which is then a buffer of four outputs.  The 256 blocks of the launch are
+    // Channel contraction split into KP = 1 << kshift parts (2 or 4): item v = brick * KP + part; a block's
+    // items vb, vb + gridDim.x, ... all take the same part of the input channels (gridDim.x is a multiple of 8)
+    // and leave a bias-free partial output in slab kpart of y, which is then a buffer of KP outputs.  The 256 blocks of the launch are
     // dealt out so that an XCD (dispatch index mod 8) works on ONE output-channel tile and as few parts as
     // possible: the transformed weights of the layer (12.6 MB at 256 -> 256) do not fit an XCD's L2, the
     // 1.6 MB of one tile and two parts do.
     if (kshift) {
         const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, j = lin >> 3;     // j: 0..31
         const int P = 8 / (int)gridDim.y, xc = xcd % P;        // XCDs per output-channel tile (8, 4, 2 or 1)
+        const int KP = 1 << kshift;                            // channel parts (2 or 4)
         cot = xcd / P;
         int kp, slot;
-        if (P >= 4) kp = xc & 3, slot = (xc >> 2) * 32 + j;
-        else if (P == 2) kp = (xc << 1) | (j & 1), slot = j >> 1;
-        else kp = j & 3, slot = j >> 2;
-        vb = slot * 4 + kp;
+        if (P >= KP) kp = xc % KP, slot = (xc / KP) * 32 + j;  // an XCD works on one part
+        else kp = xc * (KP / P) + j % (KP / P), slot = j / (KP / P);
+        vb = slot * KP + kp;
     }
     int n, z0, y0, x0;
     brick_of(vb, n, z0, y0, x0);
@@ -510,27 +510,38 @@ long k3_fwd_wino2d_bricks(int N, int D, int H, int W) {
     return (long)N * cdiv(D, 4) * cdiv(H, 2 * (16 / tpr)) * cdiv(W, 2 * tpr);
 }
 // Same contract as k3_fwd_wino_launch with ups == 1 (stat_part rows: k3_fwd_wino2d_bricks()).
-// ---- channel contraction split four ways ------------------------------------------------------------
+// ---- channel contraction split -----------------------------------------------------------------------
 // A level with fewer (brick, output-channel tile) units than CUs runs one round of blocks that each walk all
 // of Cin: 256 -> 256 @10x12x10, batch 8 = 192 blocks of 32 chunks on 256 CUs, 0.20 ms at 44 % of the peak.
 // Cut into quarters of the input channels the same work is 768 items = three per CU as one chunk stream
 // (24 chunks instead of 32 per block); each item leaves a partial output in a buffer of four, and
-// w2d_ksum_k adds them in a fixed order, adds the bias and forms the BatchNorm sums of its rows.
-constexpr int W2_KPARTS = 4, W2_KSUM_BLOCKS = 256;
+// w2d_ksum_k adds them in a fixed order, adds the bias and forms the BatchNorm sums of its rows.  Two parts
+// where the units are a few rounds of blocks with a last round half empty (128 -> 128 @20x24x20, batch 8:
+// 640 units = 3 rounds for the work of 2.5; as 1280 items exactly 5 per CU).
+constexpr int W2_KSUM_BLOCKS = 256;
+// SIV_W2KSPLIT (build flag): 0 = never split, 2 = four parts only
 #ifndef SIV_W2KSPLIT
 #define SIV_W2KSPLIT 1
 #endif
-static bool w2d_ksplit(long nbricks, int Cin, int Cout) {
+// log2 of the number of channel parts (0: not split)
+static int w2d_kshift(long nbricks, long M, int Cin, int Cout) {
     const int nchunk = Cin / 8, ncot = Cout / 64;
-    const long g = (W2_CUS / ncot) & ~7L;
-    return SIV_W2KSPLIT && W2_CHAIN && nchunk % 8 == 0 && nchunk >= 16     // items of >= 4 chunks, an even number
-        && nbricks * ncot * 5 < W2_CUS * 4                                  // one under-filled round today
-        && (ncot == 1 || ncot == 2 || ncot == 4 || ncot == 8)              // 256 blocks, whole XCDs per output tile
-        && g < nbricks * W2_KPARTS                                         // chained
-        && 256 % (Cout / 4) == 0;                                          // w2d_ksum_k's thread layout
+    if (!SIV_W2KSPLIT || !W2_CHAIN || !(ncot == 1 || ncot == 2 || ncot == 4 || ncot == 8)    // 256 blocks, whole XCDs per output tile
+        || 256 % (Cout / 4) != 0)                                                             // w2d_ksum_k's thread layout
+        return 0;
+    const long g = W2_CUS / ncot, units = nbricks * ncot;
+    // one under-filled round today: four parts (items of >= 4 chunks, an even number; chained)
+    if (units * 5 < W2_CUS * 4 && nchunk % 8 == 0 && nchunk >= 16 && g < nbricks * 4) return 2;
+    // a few rounds, the last one at most 60 % full, and twice the output is little to move: two parts
+    const long rounds = cdiv(units, W2_CUS);
+    if (SIV_W2KSPLIT != 2 && units > W2_CUS && rounds <= 4 && units * 10 <= (rounds * 10 - 4) * W2_CUS && cdiv(2 * units, W2_CUS) < 2 * rounds
+        && nchunk % 4 == 0 && nchunk >= 8 && 2 * M * Cout * 4 <= (96L << 20))
+        return 1;
+    return 0;
 }
-// part: [4][M][Cout] -> y = bias + part[0] + part[1] + part[2] + part[3]; stat_part (optional): row blockIdx.x
-// = per-channel sum and sum of squares of the bias-free output over the block's voxels.
+// part: [KP][M][Cout] -> y = bias + (part[0] + part[1]) [+ (part[2] + part[3])]; stat_part (optional): row
+// blockIdx.x = per-channel sum and sum of squares of the bias-free output over the block's voxels.
+template <int KP>
 __global__ __launch_bounds__(256) void w2d_ksum_k(const float* __restrict__ part, const float* __restrict__ bias,
                                                   float* __restrict__ y, long M, int Cout,
                                                   float* __restrict__ stat_part) {
@@ -546,8 +557,11 @@ __global__ __launch_bounds__(256) void w2d_ksum_k(const float* __restrict__ part
     for (long v = v0 + sub; v < v1; v += vpp) {
         const float* p = part + v * Cout + 4 * q;
         const float4 a0 = *reinterpret_cast<const float4*>(p), a1 = *reinterpret_cast<const float4*>(p + slab);
-        const float4 a2 = *reinterpret_cast<const float4*>(p + 2 * slab), a3 = *reinterpret_cast<const float4*>(p + 3 * slab);
-        const float4 a = w2add(w2add(a0, a1), w2add(a2, a3));
+        float4 a = w2add(a0, a1);
+        if constexpr (KP == 4) {
+            const float4 a2 = *reinterpret_cast<const float4*>(p + 2 * slab), a3 = *reinterpret_cast<const float4*>(p + 3 * slab);
+            a = w2add(a, w2add(a2, a3));
+        }
         s1 = w2add(s1, a);
         s2.x = fmaf(a.x, a.x, s2.x); s2.y = fmaf(a.y, a.y, s2.y); s2.z = fmaf(a.z, a.z, s2.z); s2.w = fmaf(a.w, a.w, s2.w);
         *reinterpret_cast<float4*>(y + v * Cout + 4 * q) = w2add(a, bq);
@@ -567,10 +581,12 @@ __global__ __launch_bounds__(256) void w2d_ksum_k(const float* __restrict__ part
 // rows for the four partial outputs (0: the contraction is not split for this shape).
 long k3_fwd_wino2d_stat_rows(int N, int D, int H, int W, int Cin, int Cout) {
     const long nb = k3_fwd_wino2d_bricks(N, D, H, W);
-    return w2d_ksplit(nb, Cin, Cout) ? W2_KSUM_BLOCKS : nb;
+    return w2d_kshift(nb, (long)N * D * H * W, Cin, Cout) ? W2_KSUM_BLOCKS : nb;
 }
 size_t k3_fwd_wino2d_ksplit_bytes(int N, int D, int H, int W, int Cin, int Cout) {
-    return w2d_ksplit(k3_fwd_wino2d_bricks(N, D, H, W), Cin, Cout) ? (size_t)W2_KPARTS * N * D * H * W * Cout * sizeof(float) : 0;
+    const long M = (long)N * D * H * W;
+    const int ks = w2d_kshift(k3_fwd_wino2d_bricks(N, D, H, W), M, Cin, Cout);
+    return ks ? ((size_t)M * Cout * sizeof(float)) << ks : 0;
 }
 
 // kws / kws_bytes: room for the four partial outputs of the split contraction (NULL / too small: not split).
@@ -606,10 +622,11 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
     }
     const size_t kneed = k3_fwd_wino2d_ksplit_bytes(N, D, H, W, Cin, Cout);
     const bool ksplit = kneed > 0 && kws != nullptr && kws_bytes >= kneed && (((uintptr_t)kws) & 15) == 0;
+    const int kshift = ksplit ? w2d_kshift(nbricks, (long)N * D * H * W, Cin, Cout) : 0;
     long nitems = nbricks;
     if (ksplit) {
-        nitems = nbricks * W2_KPARTS;
-        nblk = (W2_CUS / ncot) & ~7L;
+        nitems = nbricks << kshift;
+        nblk = W2_CUS / ncot;
     }
     auto kern = tpr == 5 ? k3_fwd_wino2d<5, SIV_W2ROUNDS> : k3_fwd_wino2d<4, SIV_W2ROUNDS>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -619,10 +636,13 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
     }
     kern<<<dim3((unsigned)nblk, (unsigned)(Cout / 64)), 512, W2Cfg::LDS_BYTES, s>>>(
         x, wpk, bias, ksplit ? (float*)kws : y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, (int)nitems, stat_part,
-        ksplit ? 2 : 0);
+        kshift);
     SIV_CHECK_LAUNCH("conv3d_k3(winograd 2-D)");
     if (ksplit) {
-        w2d_ksum_k<<<W2_KSUM_BLOCKS, 256, 0, s>>>((const float*)kws, bias, y, (long)N * D * H * W, Cout, stat_part);
+        if (kshift == 2)
+            w2d_ksum_k<4><<<W2_KSUM_BLOCKS, 256, 0, s>>>((const float*)kws, bias, y, (long)N * D * H * W, Cout, stat_part);
+        else
+            w2d_ksum_k<2><<<W2_KSUM_BLOCKS, 256, 0, s>>>((const float*)kws, bias, y, (long)N * D * H * W, Cout, stat_part);
         SIV_CHECK_LAUNCH("conv3d_k3(winograd 2-D, sum of the channel parts)");
     }
     return SIV_OK;

@@ -139,6 +139,8 @@ CONV_CASES = [
     # (768 / 384 items chained three per block) and a second kernel adds the partial outputs; forward and
     # input gradient, four and two output-channel tiles, 16 and 32 chunks
     (128, 256, (10, 12, 10), 8, 1, 6), (256, 128, (10, 12, 10), 8, 1, 0),
+    # ... and two ways where the last of a few rounds of blocks would be at most 60 % full (320 units -> 640 items)
+    (128, 128, (20, 24, 20), 4, 1, 6),
     # the same wide shapes through the generic kernels (cross-check of the dispatcher)
     (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
 ]
@@ -487,6 +489,7 @@ def test_add_act(B, shape):
     (32, 64, (20, 24, 40), 5, 1, 6, True),
     # ... and from the kernel that adds the four partial outputs of a split channel contraction
     (256, 256, (10, 12, 10), 8, 1, 0, True), (128, 128, (10, 12, 10), 8, 1, 6, False),
+    (128, 128, (20, 24, 20), 4, 1, 0, True),           # ... two partial outputs
     # ... and the product form of the upsampled kernel (forced by path 6; one-plane bricks, 20-wide variant)
     (64, 128, (8, 8, 16), 1, 2, 6, True), (16, 64, (10, 24, 20), 1, 2, 6, False), (8, 64, (6, 10, 14), 2, 2, 6, True),
     # ... with a partial output-channel tile (16, 32, 80 channels), both forms, and under the split-bf16 path
