@@ -1134,6 +1134,11 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
     const int ci0 = blockIdx.y * C::NT;
     const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
     const int nstep = (Cout / C::CK) * 4;                       // (chunk, u along D)
+    // gridDim.z > 1 (box form only): block z walks its share of the steps and leaves a partial dx in slab z
+    // of a buffer of gridDim.z outputs (added up by the caller's next kernel)
+    const int s_begin = BOX ? (int)blockIdx.z * (nstep / (int)gridDim.z) : 0;
+    const int s_end = BOX ? s_begin + nstep / (int)gridDim.z : nstep;
+    if (BOX) dx += (long)blockIdx.z * N * (D >> 1) * (H >> 1) * (W >> 1) * Cin;
 
     // LDS offset of this lane's A row for tap (u_h, u_w) = (-1, -1); with SPLIT three of them, one per
     // A operand (pieces h|h, m|h, l|m by lane half)
@@ -1236,7 +1241,7 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
         }
         return mk;
     };
-    unsigned nextmask = load_halo(0);
+    unsigned nextmask = load_halo(s_begin);
 #define SIV_PIN(V) asm volatile("" : "+v"((V).x), "+v"((V).y), "+v"((V).z), "+v"((V).w))
 #pragma unroll
     for (int i = 0; i < PD; ++i) {
@@ -1244,7 +1249,7 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
             bxr[i] = wlq[i * 256];
             byr[i] = wlq[i * 256 + 128];
         } else if constexpr (BOX) {
-            bring[i] = buf_load16(wrs, wvo, wstep(0) + i * C::SLICE * 4);
+            bring[i] = buf_load16(wrs, wvo, wstep(s_begin) + i * C::SLICE * 4);
         } else {
             bring[i] = *reinterpret_cast<const float4*>(wlane + i * C::SLICE);
         }
@@ -1263,7 +1268,7 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
-    for (int step = 0; step < nstep; ++step) {
+    for (int step = s_begin; step < s_end; ++step) {
         curmask = nextmask;
         SIV_UDS(0);
         __syncthreads();  // previous step's MFMAs are done with the planes
@@ -1314,7 +1319,7 @@ __global__ __launch_bounds__(256, 2) void k2_up_dgrad(const float* __restrict__ 
             __syncthreads();
         }
         SIV_UDS(5);
-        nextmask = load_halo(step + 1 < nstep ? step + 1 : step);
+        nextmask = load_halo(step + 1 < s_end ? step + 1 : step);
         SIV_UDS(6);
         if constexpr (SPLIT) {
             const uint4* wq = wlq + (long)step * C::TAPS * 256;
@@ -1772,9 +1777,43 @@ size_t k2_up_dgrad_ws_bytes(int Cin, int Cout) {   // sized for the split-bf16 p
     return ((size_t)((Cin + 63) / 64) * (Cout / 8) * 64 + 4) * 4096;
 }
 
+// dx = part[0] + part[1] (+ part[2] + part[3]), 16 bytes per thread and pass
+template <int KP>
+__global__ __launch_bounds__(256) void up_dgrad_ksum_k(const float* __restrict__ part, float* __restrict__ dx, long quads) {
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long)gridDim.x * 256) {
+        const float4* p = reinterpret_cast<const float4*>(part) + q;
+        float4 a = p[0], b = p[quads];
+        a = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+        if constexpr (KP == 4) {
+            const float4 c = p[2 * quads], d = p[3 * quads];
+            a = make_float4(a.x + (c.x + d.x), a.y + (c.y + d.y), a.z + (c.z + d.z), a.w + (c.w + d.w));
+        }
+        reinterpret_cast<float4*>(dx)[q] = a;
+    }
+}
+// Parts of the step loop (the contraction over the convolution's output channels and the taps along D) a
+// launch of the box form is cut into: 4 where the bricks do not fill the 2 x 256 block slots (256 -> 128
+// @20x24x20, batch 8: 160 blocks of 64 steps -> 640 of 16), 2 where a second round would be at most 60 % full
+// (128 -> 64 @40x48x40: 640 blocks -> 1280 half blocks = 2.5 rounds of half the length); 1 otherwise.
+#ifndef SIV_UPD_KSPLIT
+#define SIV_UPD_KSPLIT 1
+#endif
+static int up_dgrad_parts(long nblk_total, int Cout, long dx_elems) {
+    const int nchunk = Cout / 8;
+    if (!SIV_UPD_KSPLIT || up_dgrad_group_shift(nchunk) != 2) return 1;         // whole groups of four chunks per part
+    const long slots = 512;
+    const int ngroup = nchunk / 4;
+    if (nblk_total * 5 < slots * 2 && ngroup % 4 == 0) return 4;
+    const long rounds = cdiv(nblk_total, slots);
+    if (nblk_total > slots && rounds <= 3 && nblk_total * 10 <= (rounds * 10 - 4) * slots
+        && cdiv(2 * nblk_total, slots) < 2 * rounds && ngroup % 2 == 0 && 2 * dx_elems * 4 <= (96L << 20))
+        return 2;
+    return 1;
+}
+
 template <int LBD, int LBH, int LBW, bool SPLIT, bool BOX = false>
 static int up_dgrad_cfg(const float* dy, const void* wp, float* dx, int N, int D, int H, int W, int Cin,
-                        int Cout, hipStream_t s) {
+                        int Cout, hipStream_t s, void* kws = nullptr, size_t kws_bytes = 0) {
     using C = UdCfg<LBD, LBH, LBW>;
     const int nbd = (int)cdiv(D / 2, LBD), nbh = (int)cdiv(H / 2, LBH), nbw = (int)cdiv(W / 2, LBW);
     const long nblk = (long)N * nbd * nbh * nbw;
@@ -1788,9 +1827,21 @@ static int up_dgrad_cfg(const float* dy, const void* wp, float* dx, int N, int D
         set_error("conv3d_k3_dgrad(upsampled): cannot reserve %zu bytes of LDS", C::LDS_BYTES);
         return SIV_EHIP;
     }
-    k2_up_dgrad<LBD, LBH, LBW, SPLIT, BOX><<<dim3((unsigned)nblk, (unsigned)((Cin + 63) / 64)), 256, C::LDS_BYTES, s>>>(
-        dy, wp, dx, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
+    const long dx_elems = (long)N * (D / 2) * (H / 2) * (W / 2) * Cin;
+    int parts = BOX && Cin % 4 == 0 ? up_dgrad_parts(nblk * ((Cin + 63) / 64), Cout, dx_elems) : 1;
+    if (parts > 1 && (kws == nullptr || kws_bytes < (size_t)parts * dx_elems * sizeof(float) || (((uintptr_t)kws) & 15) != 0))
+        parts = 1;
+    k2_up_dgrad<LBD, LBH, LBW, SPLIT, BOX><<<dim3((unsigned)nblk, (unsigned)((Cin + 63) / 64), (unsigned)parts), 256, C::LDS_BYTES, s>>>(
+        dy, wp, parts > 1 ? (float*)kws : dx, N, D, H, W, Cin, Cout, nbd, nbh, nbw);
     SIV_CHECK_LAUNCH("conv3d_k3_dgrad(upsampled)");
+    if (parts > 1) {
+        const long quads = dx_elems / 4;
+        long g = cdiv(quads, 256L * 4);
+        if (g > 2048) g = 2048;
+        if (parts == 4) up_dgrad_ksum_k<4><<<(unsigned)g, 256, 0, s>>>((const float*)kws, dx, quads);
+        else up_dgrad_ksum_k<2><<<(unsigned)g, 256, 0, s>>>((const float*)kws, dx, quads);
+        SIV_CHECK_LAUNCH("conv3d_k3_dgrad(upsampled, sum of the parts)");
+    }
     return SIV_OK;
 }
 
@@ -1830,7 +1881,9 @@ int k2_up_dgrad_launch(const float* dy, const float* w, float* dx, int N, int D,
         return up_dgrad_cfg<4, 8, 8, true>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);
     }
     if (box) {
-        if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, false, true>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);
+        void* kws = ws_tail(ws, ws_bytes, k2_up_dgrad_ws_bytes(Cin, Cout));
+        const size_t kws_bytes = ws_tail_bytes(ws_bytes, k2_up_dgrad_ws_bytes(Cin, Cout));
+        if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, false, true>(dy, wpk, dx, N, D, H, W, Cin, Cout, s, kws, kws_bytes);
         // whole cache lines per staged voxel where the channel groups are whole (32) and the lane offsets,
         // shifted by up to nine planes, stay clear of the marker for voxels outside the sample
         if (SIV_UPD_LINE && Cout % 32 == 0 && (long)(D + 10) * H * W * Cout * 4 < (1L << 30)) {
@@ -1851,7 +1904,7 @@ int k2_up_dgrad_launch(const float* dy, const float* w, float* dx, int N, int D,
             SIV_CHECK_LAUNCH("conv3d_k3_dgrad(upsampled, whole lines)");
             return SIV_OK;
         }
-        return up_dgrad_cfg<4, 8, 8, false, true>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);
+        return up_dgrad_cfg<4, 8, 8, false, true>(dy, wpk, dx, N, D, H, W, Cin, Cout, s, kws, kws_bytes);
     }
     if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, false>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);
     return up_dgrad_cfg<4, 8, 8, false>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);

@@ -141,6 +141,9 @@ CONV_CASES = [
     (128, 256, (10, 12, 10), 8, 1, 6), (256, 128, (10, 12, 10), 8, 1, 0),
     # ... and two ways where the last of a few rounds of blocks would be at most 60 % full (320 units -> 640 items)
     (128, 128, (20, 24, 20), 4, 1, 6),
+    # four-plane box form of the upsampled input gradient with its step loop cut in two (520 one-brick samples:
+    # a second round of blocks would be 2 % full) -- the four-part cut is taken by the small 10-wide cases above
+    (16, 64, (4, 4, 20), 520, 2, 6),
     # the same wide shapes through the generic kernels (cross-check of the dispatcher)
     (64, 64, (5, 7, 9), 1, 1, 1), (8, 64, (4, 6, 4), 1, 2, 1),
 ]
