@@ -204,6 +204,43 @@ def test_conv_wgrad_accumulates(B, path, ups):
     check(db, bias0 + db_ref, "bias grad accumulate")
 
 
+def test_split_contraction_falls_back_without_workspace_room(B):
+    """The deep-level launches that cut their channel contraction into parts keep the partial outputs in the
+    tail of the workspace; with a workspace that only holds the packed weights they run unsplit.  Both forms
+    are checked against each other (summation order differs: tolerance of the other convolution tests) for
+    the forward, the forward with statistics and the input gradient behind an upsample."""
+    import siv._lib as L
+    from siv.backend import cl, _p
+    gen = torch.Generator().manual_seed(5)
+    N, D, H, W, C = 8, 10, 12, 10, 256
+    x = cl(dev(rnd(gen, N, C, D, H, W)))
+    w = cl(dev(rnd(gen, C, C, 3, 3, 3) * 0.05))
+    b = dev(rnd(gen, C))
+    small = torch.empty(20 << 20, dtype=torch.uint8, device="cuda")      # 12.6 MB of packed weights fit, 39 MB more do not
+    y_ref = B.conv3d_k3_fwd(x, w, b, 1)
+    assert B.last_conv_kernel() == "wino2d"
+    y = torch.empty_like(y_ref)
+    L.check(B.lib.siv_conv3d_k3_fwd(_p(x), _p(w), _p(b), _p(y), N, D, H, W, C, C, 1, small.data_ptr(), small.numel(),
+                                    B._stream(x)), "siv_conv3d_k3_fwd")
+    check(y, y_ref, "forward, unsplit against split")
+    y2, mean_ref, var_ref = B.conv3d_k3_fwd_stats(x, w, b, 1, None, None, None, 0.1)
+    mean, var = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    L.check(B.lib.siv_conv3d_k3_fwd_bnstats(_p(x), _p(w), _p(b), _p(y), N, D, H, W, C, C, 1, _p(mean), _p(var), None, None,
+                                            None, 0.1, small.data_ptr(), small.numel(), B._stream(x)),
+            "siv_conv3d_k3_fwd_bnstats")
+    check(y, y2, "forward with statistics, unsplit against split")
+    check(mean, mean_ref, "mean")
+    check(var, var_ref, "var")
+    # input gradient behind an upsample: 256 -> 128 @20x24x20 (four parts of the step loop)
+    dy = cl(dev(rnd(gen, N, 128, 2 * D, 2 * H, 2 * W)))
+    wu = cl(dev(rnd(gen, 128, C, 3, 3, 3) * 0.05))
+    dx_ref = B.conv3d_k3_dgrad(dy, wu, 2)
+    dx = torch.empty_like(dx_ref)
+    L.check(B.lib.siv_conv3d_k3_dgrad_up(_p(dy), _p(wu), _p(dx), N, 2 * D, 2 * H, 2 * W, C, 128, small.data_ptr(),
+                                         small.numel(), B._stream(dy)), "siv_conv3d_k3_dgrad_up")
+    check(dx, dx_ref, "upsampled input gradient, unsplit against split")
+
+
 def test_conv_rejects_bad_arguments(B):
     import siv._lib as L
     x = torch.zeros(1, 4, 3, 3, 3, device="cuda")
