@@ -1803,7 +1803,7 @@ static int up_dgrad_parts(long nblk_total, int Cout, long dx_elems) {
     if (!SIV_UPD_KSPLIT || up_dgrad_group_shift(nchunk) != 2) return 1;         // whole groups of four chunks per part
     const long slots = 512;
     const int ngroup = nchunk / 4;
-    if (nblk_total * 5 < slots * 2 && ngroup % 4 == 0) return 4;
+    if (nblk_total * 5 < slots * 2 && ngroup % 2 == 0) return ngroup % 4 == 0 ? 4 : 2;
     const long rounds = cdiv(nblk_total, slots);
     if (nblk_total > slots && rounds <= 3 && nblk_total * 10 <= (rounds * 10 - 4) * slots
         && cdiv(2 * nblk_total, slots) < 2 * rounds && ngroup % 2 == 0 && 2 * dx_elems * 4 <= (96L << 20))
@@ -1852,7 +1852,12 @@ int k2_up_dgrad_launch(const float* dy, const float* w, float* dx, int N, int D,
     // the box form on request and from 32 K output voxels upwards (1.35x faster at the benchmark sizes);
     // tiny volumes keep the 16-tap form
     if (Cin % 64 != 0) split = false;
-    const bool box = !split && (force_box || (long)N * D * H * W >= (1L << 15));
+    // (also where the box form's step loop can be cut into parts: a small volume is a handful of bricks)
+    const bool w10 = up_wide10(W);
+    const long nbricks = (long)N * cdiv(D / 2, w10 ? 2 : 4) * cdiv(H / 2, w10 ? 12 : 8) * cdiv(W / 2, w10 ? 10 : 8);
+    const long dx_elems = (long)N * (D / 2) * (H / 2) * (W / 2) * Cin;
+    const int box_parts = split || Cin % 4 != 0 ? 1 : up_dgrad_parts(nbricks * ((Cin + 63) / 64), Cout, dx_elems);
+    const bool box = !split && (force_box || (long)N * D * H * W >= (1L << 15) || box_parts > 1);
     SIV_CHECK_WS(k2_up_dgrad_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3_dgrad(upsampled)");
     bool need_pack;
     void* wpk = pack_slot(w, split ? PF_UPD_B3 : box ? PF_UPD_BOX : PF_UPD, 0, 1, Cin, Cout,
@@ -1886,7 +1891,7 @@ int k2_up_dgrad_launch(const float* dy, const float* w, float* dx, int N, int D,
         if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, false, true>(dy, wpk, dx, N, D, H, W, Cin, Cout, s, kws, kws_bytes);
         // whole cache lines per staged voxel where the channel groups are whole (32) and the lane offsets,
         // shifted by up to nine planes, stay clear of the marker for voxels outside the sample
-        if (SIV_UPD_LINE && Cout % 32 == 0 && (long)(D + 10) * H * W * Cout * 4 < (1L << 30)) {
+        if (SIV_UPD_LINE && box_parts == 1 && Cout % 32 == 0 && (long)(D + 10) * H * W * Cout * 4 < (1L << 30)) {
             using C = UlCfg;
             const int nbd = (int)cdiv(D / 2, C::LBD), nbh = (int)cdiv(H / 2, C::LBH), nbw = (int)cdiv(W / 2, C::LBW);
             const long nblk = (long)N * nbd * nbh * nbw;
