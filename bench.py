@@ -4,6 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Started plainly with --gpus N > 1 (no RANK / WORLD_SIZE in the environment) it is its own launcher: the
+parent starts N fresh child processes, one per GPU, before it has imported torch or touched a GPU, and only
+waits for them (it never becomes a rank and never replaces itself); rank 0's child prints the JSON line.
+Under torch.distributed.run the ranks already exist and each process is one of them.
+
 A "step" is one full iteration of utils/my_trainer.py:242-325 on one batch of synthetic volumes
 that is already resident in HBM.  Workload: BASELINE.json configs[2] -- 80x96x80 fp32, z=1200,
 SoftIntroVAE(64,[[64,1,2],[128,1,2],[256,2,2]]), batch 8 per GPU (weak scaling: global batch
@@ -16,6 +21,8 @@ CPU oracle timed on the host cores on a bounded sample.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,12 +31,78 @@ for p in (ROOT, os.path.join(ROOT, "soft-intro-vae-for-3d-mri_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=None, help="volumes per GPU (default 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fc", action="store_true", help="skip the FC-latent z=600 side measurement")
+    ap.add_argument("--graph", action="store_true",
+                    help="single GPU: capture the iteration in a HIP graph and replay it (the per-kernel "
+                         "event timing of the roofline fields is then taken from two eager iterations)")
+    ap.add_argument("--split-bf16", action="store_true",
+                    help="also time the opt-in conv path 5 (fp32 products from bf16 triples); never the headline")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="NOT a measurement: run the launcher and the rank code on CPU over gloo with a narrow "
+                         "model on 16x24x16 volumes; the arithmetic backend is the class named by "
+                         "SIV_BENCH_BACKEND=module:Class (the test suite passes its checker), there is no "
+                         "built-in CPU path")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Start ``n`` ranks of this script as fresh child processes (RANK / LOCAL_RANK = 0..n-1, one rendezvous
+    on 127.0.0.1) and wait for them.  Called before torch is imported: the parent holds no GPU state, does
+    not join the job and does not replace itself.  Returns the first non-zero exit code (the remaining
+    ranks are then stopped), else 0.  stdout is inherited, so rank 0's JSON line is the parent's output."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver supports dmabuf IPC only
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live and rc == 0:
+            time.sleep(0.2)
+            for p in list(live):
+                code = p.poll()
+                if code is not None:
+                    live.remove(p)
+                    if code != 0:
+                        rc = code
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
+
+
+if __name__ == "__main__":
+    _a = parse_args()
+    if _a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(_a.gpus, sys.argv[1:]))
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MODEL = (64, [[64, 1, 2], [128, 1, 2], [256, 2, 2]])     # z-1200main.py:158
 DIMS = (80, 96, 80)
 PER_GPU_BATCH = 8
+REHEARSAL_MODEL = (4, [[4, 1, 2], [8, 1, 2], [8, 2, 2]])     # --rehearse-cpu only
+REHEARSAL_DIMS = (16, 24, 16)
 FP32_PEAK_TFLOPS = 157.3                                   # MI355X fp32 matrix/vector peak
 HBM_PEAK_TBS = 8.0                                         # MI355X HBM3E peak (about 6.3 TB/s reachable by a copy)
 # dominant kernel: 3x3x3 conv 64->64 at 80x96x80 (60 % of the model's FLOPs):
@@ -61,11 +134,11 @@ def step_flops_per_volume():
     return alg, iss
 
 
-def build_model(device):
+def build_model(device, model_cfg=MODEL):
     import siv.models.models as models
     import siv.utils.my_trainer as trainer
     torch.manual_seed(82)                                  # z-1200main.py:152
-    net = models.SoftIntroVAE(*MODEL)
+    net = models.SoftIntroVAE(*model_cfg)
     torch.manual_seed(77)                                  # utils/my_trainer.py:160-171
     net.apply(trainer.init_weights_he)
     return net.to(device).train()
@@ -162,19 +235,11 @@ def fc_config_entry(device, steps=5, warmup=2):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="volumes per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fc", action="store_true", help="skip the FC-latent z=600 side measurement")
-    ap.add_argument("--graph", action="store_true",
-                    help="single GPU: capture the iteration in a HIP graph and replay it (the per-kernel "
-                         "event timing of the roofline fields is then taken from two eager iterations)")
-    ap.add_argument("--split-bf16", action="store_true",
-                    help="also time the opt-in conv path 5 (fp32 products from bf16 triples); never the headline")
-    args = ap.parse_args()
+    args = parse_args()
+    rehearse = args.rehearse_cpu
+    if args.batch is None:
+        args.batch = 2 if rehearse else PER_GPU_BATCH
+    model_cfg, dims = (REHEARSAL_MODEL, REHEARSAL_DIMS) if rehearse else (MODEL, DIMS)
 
     # keep stdout for the one JSON line: library banners (RCCL prints its version on the first
     # communicator) go to stderr
@@ -188,25 +253,48 @@ def main():
     from siv.optim import FlatAdam
     from siv.parallel import GradSync, init_process_group
 
-    rank, local_rank, world = init_process_group("nccl")
+    if rehearse:
+        # launcher / rank-code rehearsal on CPU: the arithmetic comes from an injected backend class
+        spec = os.environ.get("SIV_BENCH_BACKEND")
+        if not spec:
+            raise SystemExit("--rehearse-cpu needs SIV_BENCH_BACKEND=module:Class (there is no built-in CPU path)")
+        import importlib
+        mod, cls = spec.split(":")
+        sb.set_backend(getattr(importlib.import_module(mod), cls)())
+        torch.set_num_threads(2)
+    rank, local_rank, world = init_process_group("gloo" if rehearse else "nccl")
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    if rehearse:
+        device = torch.device("cpu")
+    else:
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
     B = sb.get_backend()
-    assert B.name == "hip"
+    assert rehearse or B.name == "hip"
 
-    net = build_model(device)
+    net = build_model(device, model_cfg)
     sync = GradSync(device)
     sync.broadcast_(net)                                   # replicas start from rank 0's parameters and buffers
     opt_e = FlatAdam(net.encoder.parameters(), lr=2e-4)
     opt_d = FlatAdam(net.decoder.parameters(), lr=2e-4)
     step = trainer.SoftIntroStep(net, opt_e, opt_d, 1.0, 1024.0, 0.75, 1e-8, None, sync)
-    srng.manual_seed(77, rank)
+    if rehearse:
+        class _HostDraws:                                  # explicit host tensors in place of the device generator
+            g = torch.Generator().manual_seed(77 + rank)
+
+            def mask(self, shape, p):
+                return (torch.rand(shape, generator=self.g) >= p).float()
+
+            def eps(self, shape):
+                return torch.randn(shape, generator=self.g)
+        srng.set_rng(srng.ReplayRng(_HostDraws()))
+    else:
+        srng.manual_seed(77, rank)
 
     gen = torch.Generator().manual_seed(103 + rank)        # data seed, z-1200main.py:63
     n_batches = 2
-    batches = [torch.rand(args.batch, 1, *DIMS, generator=gen).to(device) for _ in range(n_batches)]
+    batches = [torch.rand(args.batch, 1, *dims, generator=gen).to(device) for _ in range(n_batches)]
 
     # live timing of the dominant kernel: HIP events on the launch stream around every forward
     # launch of the 64->64 conv at full resolution inside the timed region
@@ -230,49 +318,61 @@ def main():
     # the layer runs through conv3d_k3_fwd_stats in training mode (convolution + BatchNorm statistics
     # in one C call: the event pair then also spans the weight-packing and the statistics-finalize
     # launches, ~15 us of 4.5 ms) and through conv3d_k3_fwd otherwise
-    B.conv3d_k3_fwd = timed(B.conv3d_k3_fwd)
-    B.conv3d_k3_fwd_stats = timed(B.conv3d_k3_fwd_stats)
+    if not rehearse:
+        B.conv3d_k3_fwd = timed(B.conv3d_k3_fwd)
+        B.conv3d_k3_fwd_stats = timed(B.conv3d_k3_fwd_stats)
 
-    # ... and of three HBM-bound members of the step: the BatchNorm+LeakyReLU(+AvgPool) backward of a 64-channel
-    # full-resolution layer (reads y and the pooled dout, writes dy), the stem's fused BatchNorm backward and the decoder's 64 -> 1 output convolution with its BatchNorm prologue (reads 157 MB, writes 2.5 MB per volume)
+    # ... and three HBM-bound members of the step: the BatchNorm+LeakyReLU(+AvgPool) backward of a 64-channel
+    # full-resolution layer, the stem's fused BatchNorm backward and the decoder's 64 -> 1 output convolution with
+    # its BatchNorm prologue.  They are timed in two extra iterations AFTER the timed region with the
+    # weight gradients kept on the main stream, so that nothing shares the chip with them (inside the
+    # timed region a side-stream weight gradient time-shares the CUs and the event pair would measure that).
+    # Each entry carries the algorithmic bytes (every tensor once) and the bytes its passes really move.
     hbm_events = {"bn_act_bwd": [], "stem_bn_bwd": [], "conv_64_to_1": []}
+    hbm_on = {"on": False}
 
     def timed_hbm(orig, name, hit_fn, bytes_fn):
         def call(*a, **k):
-            if not (recording["on"] and hit_fn(*a)):
+            if not (hbm_on["on"] and hit_fn(*a)):
                 return orig(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = orig(*a, **k)
             e1.record()
-            hbm_events[name].append((e0, e1, bytes_fn(*a)))
+            hbm_events[name].append((e0, e1) + tuple(bytes_fn(*a)))
             return out
         return call
 
-    B.bn_act_bwd = timed_hbm(
-        B.bn_act_bwd, "bn_act_bwd",
-        # args after (dout, y): mean, var, gamma, beta, res, keep, p, slope, pool, eps, ...
-        # the pooled BatchNorm behind the first wide encoder convolution: dout at 40x48x40, y and dy at 80x96x80
-        lambda dout, y, *r: y.shape[1] == 64 and tuple(y.shape[2:]) == DIMS and r[8] == 2 and r[4] is None,
-        lambda dout, y, *r: 2 * y.numel() * 4 + dout.numel() * 4)
-    # the encoder stem's BatchNorm backward (its convolution output is recomputed, not read): dout and the
-    # dropout mask read, the gradient of the convolution output written
-    B.conv1_bnact_bwd = timed_hbm(
-        B.conv1_bnact_bwd, "stem_bn_bwd",
-        lambda dout, *r: dout.shape[1] == 64 and tuple(dout.shape[2:]) == DIMS,
-        lambda dout, x, w, bias, mean, var, gamma, beta, keep, *r: 2 * dout.numel() * 4 + (dout.numel() if keep is not None else 0))
-    # (the output convolution applies the BatchNorm + LeakyReLU of the block in front while it loads:
-    # same bytes -- the raw 64-channel tensor read once, one channel written)
-    B.bnact_conv_to1_fwd = timed_hbm(
-        B.bnact_conv_to1_fwd, "conv_64_to_1",
-        lambda x, *r: x.shape[1] == 64 and tuple(x.shape[2:]) == DIMS,
-        lambda x, *r: (x.numel() + x.numel() // 64) * 4)
+    if not rehearse:
+        B.bn_act_bwd = timed_hbm(
+            B.bn_act_bwd, "bn_act_bwd",
+            # args after (dout, y): mean, var, gamma, beta, res, keep, p, slope, pool, eps, ...
+            # the pooled BatchNorm behind the first wide encoder convolution: dout at 40x48x40, y and dy at
+            # 80x96x80.  Algorithmic: y and dout read, dy written.  Moved: the reduction pass reads y and dout,
+            # the apply pass reads them again and writes dy.
+            lambda dout, y, *r: y.shape[1] == 64 and tuple(y.shape[2:]) == DIMS and r[8] == 2 and r[4] is None,
+            lambda dout, y, *r: (2 * y.numel() * 4 + dout.numel() * 4, 3 * y.numel() * 4 + 2 * dout.numel() * 4))
+        # the encoder stem's BatchNorm backward (its convolution output is recomputed, not read).  Algorithmic:
+        # dout (and a stored mask) read, the gradient of the convolution output written.  Moved: dout (and the
+        # mask) read by both passes.
+        B.conv1_bnact_bwd = timed_hbm(
+            B.conv1_bnact_bwd, "stem_bn_bwd",
+            lambda dout, *r: dout.shape[1] == 64 and tuple(dout.shape[2:]) == DIMS,
+            lambda dout, x, w, bias, mean, var, gamma, beta, keep, *r: (
+                2 * dout.numel() * 4 + (dout.numel() if torch.is_tensor(keep) else 0),
+                3 * dout.numel() * 4 + (2 * dout.numel() if torch.is_tensor(keep) else 0)))
+        # (the output convolution applies the BatchNorm + LeakyReLU of the block in front while it loads:
+        # the raw 64-channel tensor read once, one channel written; one pass)
+        B.bnact_conv_to1_fwd = timed_hbm(
+            B.bnact_conv_to1_fwd, "conv_64_to_1",
+            lambda x, *r: x.shape[1] == 64 and tuple(x.shape[2:]) == DIMS,
+            lambda x, *r: ((x.numel() + x.numel() // 64) * 4, (x.numel() + x.numel() // 64) * 4))
 
     graphed = None
 
     def one_step(i):
         real = batches[i % n_batches]
-        noise = srng.get_rng().eps(net.latent_shape(real.size(0), DIMS), device)
+        noise = srng.get_rng().eps(net.latent_shape(real.size(0), dims), device)
         return (graphed or step)(real, noise)
 
     multi = dist.is_initialized()       # world > 1, or a forced one-rank rehearsal of the RCCL path
@@ -280,7 +380,8 @@ def main():
     def barrier():
         if multi:
             dist.barrier()
-        torch.cuda.synchronize()
+        if device.type == "cuda":
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         one_step(i)
@@ -292,7 +393,7 @@ def main():
             one_step(i)
         barrier()
         recording["on"] = False
-        graphed = trainer.GraphedSoftIntroStep(step, batches[0].shape, net.latent_shape(args.batch, DIMS), device)
+        graphed = trainer.GraphedSoftIntroStep(step, batches[0].shape, net.latent_shape(args.batch, dims), device)
         one_step(0)
         barrier()
     recording["on"] = graphed is None
@@ -311,6 +412,18 @@ def main():
     stats = dict(zip(trainer.STAT_NAMES, last.cpu().tolist()))
     if not all(v == v for v in stats.values()):
         raise SystemError(f"NaN in losses: {stats}")
+
+    if not rehearse:
+        # the HBM-bound members, alone on the chip (see above): two more iterations, not part of `value`
+        import siv.ops as sops
+        saved_overlap = sops.OVERLAP_WGRAD
+        sops.OVERLAP_WGRAD = False
+        hbm_on["on"] = True
+        for i in range(2):
+            step(batches[i % n_batches], srng.get_rng().eps(net.latent_shape(args.batch, dims), device))
+        barrier()
+        hbm_on["on"] = False
+        sops.OVERLAP_WGRAD = saved_overlap
 
     # Second, separately reported measurement: the same iteration with the opt-in kernels that form
     # their fp32 products from bf16 triples on the bf16 matrix cores (conv path 5).  It is NOT the
@@ -375,13 +488,19 @@ def main():
         roof_hbm = {}
         for name, evs in hbm_events.items():
             if evs:
-                ms = [e0.elapsed_time(e1) for e0, e1, _ in evs]
-                byts = sum(b for _, _, b in evs) / len(evs)
-                gbs = byts / (sum(ms) / len(ms) * 1e-3) / 1e9
+                ms = [e[0].elapsed_time(e[1]) for e in evs]
+                avg = sum(ms) / len(ms)
+                byts = sum(e[2] for e in evs) / len(evs)
+                moved = sum(e[3] for e in evs) / len(evs)
+                gbs = byts / (avg * 1e-3) / 1e9
                 roof_hbm[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s",
                                   "frac": round(gbs / (HBM_PEAK_TBS * 1e3), 4), "launches_timed": len(ms),
-                                  "avg_launch_ms": round(sum(ms) / len(ms), 3),
-                                  "algorithmic_bytes_per_launch": int(byts)}
+                                  "avg_launch_ms": round(avg, 3),
+                                  "algorithmic_bytes_per_launch": int(byts),
+                                  "moved_bytes_per_launch": int(moved),
+                                  "moved_gbs": round(moved / (avg * 1e-3) / 1e9, 1),
+                                  "timed": "two iterations after the timed region, weight gradients on the main "
+                                           "stream (nothing else on the chip)"}
         out = {
             "metric": "MRI volumes/sec (S-IntroVAE step) at 80x96x80 z=1200",
             "value": round(vols, 4), "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
@@ -400,9 +519,17 @@ def main():
             "split_bf16_products": split,
             "losses": {k: stats[k] for k in ("lossE", "lossD", "loss_rec", "kl_real")},
         }
-        if world == 1 and not args.no_fc:
+        if rehearse:
+            # a rehearsal of the launcher and the rank code, not a measurement of anything
+            out["metric"] = "REHEARSAL (CPU, gloo, narrow model, 16x24x16): not a measurement"
+            out["data"] = "synthetic (rehearsal)"
+            out["config"]["workload"] = "launcher rehearsal: SoftIntroVAE(4,[[4,1,2],[8,1,2],[8,2,2]]) at 16x24x16"
+            out["config"]["rng"] = "host tensors"
+            for k in ("roofline", "roofline_step", "roofline_hbm"):
+                out[k] = None
+        if world == 1 and not args.no_fc and not rehearse:
             out["fc_config"] = fc_config_entry(device)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not rehearse:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()
         os.dup2(json_fd, 1)

@@ -202,3 +202,35 @@ def test_shard_rejects_indivisible_batch():
         pass
     g.world = 2
     assert g.shard(torch.arange(8).view(4, 2)).tolist() == [[4, 5], [6, 7]]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (no RANK / WORLD_SIZE in the environment) must start two
+    ranks itself and rank 0 must print the one JSON line for the two-rank job.  Run here over gloo with the
+    test-only checker backend injected (`--rehearse-cpu`): the launcher, the rendezvous, the sharded step with
+    its two gradient exchanges and the max-over-ranks timing are the code the GPU job runs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SIV_FORCE_COLLECTIVE")}
+    env["SIV_BENCH_BACKEND"] = "tests.cpu_backend:CpuCheckerBackend"
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--rehearse-cpu"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                      # exactly one line on stdout, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]
+    assert out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "weak"
+    assert all(np.isfinite(v) for v in out["losses"].values())
+
+    # a rank that fails takes the job down with a non-zero exit code instead of hanging the others
+    env_bad = dict(env)
+    del env_bad["SIV_BENCH_BACKEND"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--rehearse-cpu"], env=env_bad, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
