@@ -68,13 +68,22 @@ int siv_set_conv_path(int path);
  *                                         siv_pack_cache_invalidate() calls (weights elsewhere are never cached);
  *   siv_pack_cache_remove_weights(lo)     the range that starts at lo is no longer weight memory (freed);
  *   siv_pack_cache_invalidate()           the weights changed: forget every packing;
+ *   siv_pack_cache_invalidate_range(lo, bytes)  only the weights inside [lo, lo+bytes) changed (one optimiser's
+ *                                         flat parameter buffer): their packings are marked stale and refilled
+ *                                         in place at their next use, packings of other weights stay valid;
  *   siv_pack_cache_hits()                 number of convolution calls served from the cache (diagnostic).
  * The library allocates nothing; a full cache falls back to packing into the workspace.  Cached packings
- * are written and read in stream order: use them from one stream.  No reference counterpart. */
+ * are written and read in stream order: every CONVOLUTION call that may use the cache must be issued on one
+ * stream.  The invalidate calls are host-side bookkeeping and may be made while another stream updates the
+ * weights (the data-parallel path runs all-reduce + Adam on a side stream and invalidates that optimiser's
+ * range at once): what the caller must guarantee is that the convolution stream waits for the update before
+ * its next convolution with those weights -- the refill is then ordered behind the update.
+ * No reference counterpart. */
 int siv_pack_cache_configure(void* mem, size_t bytes);
 int siv_pack_cache_add_weights(const void* lo, size_t bytes);
 int siv_pack_cache_remove_weights(const void* lo);
 int siv_pack_cache_invalidate(void);
+int siv_pack_cache_invalidate_range(const void* lo, size_t bytes);
 long siv_pack_cache_hits(void);
 
 /* ---- 3x3x3 convolution, stride 1, zero padding 1 --------------------------------

@@ -352,7 +352,7 @@ int k3_fwd_mfma_launch(const float* x, const float* w, const float* bias, float*
     if (g > 4096) g = 4096;
     if (need_pack) {
         k3_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout, NT, flip);
-        SIV_CHECK_LAUNCH("conv3d_k3(pack weights)");
+        SIV_CHECK_PACK_LAUNCH("conv3d_k3(pack weights)", wp);
     }
 #define SIV_FWD(BD, BH, BW, WM, WN, NTT)                                                              \
     (ups == 1 ? launch_fwd<BD, BH, BW, WM, WN, NTT, 1>(x, wp, bias, y, N, D, H, W, Cin, Cout, s)       \

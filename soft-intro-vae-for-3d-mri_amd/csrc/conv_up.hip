@@ -723,7 +723,7 @@ int k2_up_fwd_launch(const float* x, const float* w, const float* bias, float* y
         void* wpk = pack_slot(w, PF_UP_PROD, 0, 0, Cin, Cout, k2_up_fwd_ws_bytes(Cin, Cout), ws, &need_pack);
         if (need_pack) {
             k2_up_pack_weights_prod<<<(unsigned)g, 256, 0, s>>>(w, (float*)wpk, Cin, Cout);
-            SIV_CHECK_LAUNCH("conv3d_k3(pack upsampled weights, product form)");
+            SIV_CHECK_PACK_LAUNCH("conv3d_k3(pack upsampled weights, product form)", wpk);
         }
         if (up_wide10(W)) return up_launch_prod<1, 6, 10>(x, wpk, bias, y, N, D, H, W, Cin, Cout, s, stat_part);
         return up_launch_prod<1, 8, 8>(x, wpk, bias, y, N, D, H, W, Cin, Cout, s, stat_part);
@@ -741,7 +741,7 @@ int k2_up_fwd_launch(const float* x, const float* w, const float* bias, float* y
             if (g > 4096) g = 4096;
             k2_up_pack_weights<<<(unsigned)g, 256, 0, s>>>(w, (float*)wpk, Cin, Cout);
         }
-        SIV_CHECK_LAUNCH("conv3d_k3(pack upsampled weights)");
+        SIV_CHECK_PACK_LAUNCH("conv3d_k3(pack upsampled weights)", wpk);
     }
     if (up_wide10(W)) return up_launch_cfg<1, 12, 10>(x, wpk, bias, y, N, D, H, W, Cin, Cout, s, stat_part, split);
     return up_launch_cfg<2, 8, 8>(x, wpk, bias, y, N, D, H, W, Cin, Cout, s, stat_part, split);
@@ -1879,7 +1879,7 @@ int k2_up_dgrad_launch(const float* dy, const float* w, float* dx, int N, int D,
             if (g > 4096) g = 4096;
             k2_up_pack_dgrad<<<(unsigned)g, 256, 0, s>>>(w, (float*)wpk, Cin, Cout);
         }
-        SIV_CHECK_LAUNCH("conv3d_k3_dgrad(pack upsampled weights)");
+        SIV_CHECK_PACK_LAUNCH("conv3d_k3_dgrad(pack upsampled weights)", wpk);
     }
     if (split) {
         if (up_wide10(W)) return up_dgrad_cfg<2, 12, 10, true>(dy, wpk, dx, N, D, H, W, Cin, Cout, s);

@@ -331,7 +331,7 @@ int k3_fwd_wino_launch(const float* x, const float* w, const float* bias, float*
     if (g > 4096) g = 4096;
     if (need_pack) {
         k3_pack_weights_wino<<<(unsigned)g, 256, 0, s>>>(w, wp, Cin, Cout, flip);
-        SIV_CHECK_LAUNCH("conv3d_k3(pack winograd weights)");
+        SIV_CHECK_PACK_LAUNCH("conv3d_k3(pack winograd weights)", wp);
     }
     const int nbd = (D + 3) / 4, nbh = (H + 7) / 8, nbw = (W + 7) / 8;
     const long nblk = (long)N * nbd * nbh * nbw;

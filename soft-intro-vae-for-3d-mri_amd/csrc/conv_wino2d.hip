@@ -602,7 +602,7 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
     const float* wpk = (const float*)pack_slot(w, PF_WINO2D, 0, flip, Cin, Cout, k3_fwd_wino2d_ws_bytes(Cin, Cout), ws, &need_pack);
     if (need_pack) {
         k3_pack_weights_wino2d<<<(unsigned)g, 256, 0, s>>>(w, const_cast<float*>(wpk), Cin, Cout, flip);
-        SIV_CHECK_LAUNCH("conv3d_k3(pack 2-D winograd weights)");
+        SIV_CHECK_PACK_LAUNCH("conv3d_k3(pack 2-D winograd weights)", wpk);
     }
     const int tpr = w2d_tpr(H, W);
     const int nbd = (D + 3) / 4, nbh = (int)cdiv(H, 2 * (16 / tpr)), nbw = (int)cdiv(W, 2 * tpr);

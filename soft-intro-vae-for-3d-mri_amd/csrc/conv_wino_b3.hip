@@ -311,7 +311,7 @@ int k3_fwd_wino_b3_launch(const float* x, const float* w, const float* bias, flo
     void* wpk = pack_slot(w, PF_WINO_B3, 0, flip, Cin, Cout, k3_fwd_wino_b3_ws_bytes(Cin, Cout), ws, &need_pack);
     if (need_pack) {
         k3_pack_weights_wino_b3<<<(unsigned)g, 256, 0, s>>>(w, (__bf16*)wpk, Cin, Cout, flip);
-        SIV_CHECK_LAUNCH("conv3d_k3(pack split-bf16 winograd weights)");
+        SIV_CHECK_PACK_LAUNCH("conv3d_k3(pack split-bf16 winograd weights)", wpk);
     }
     const int nbd = (D + 3) / 4, nbh = (H + 7) / 8, nbw = (W + 7) / 8;
     const long nblk = (long)N * nbd * nbh * nbw;

@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma_k(const float* __restrict
     const int cg = item % ncg, slab = item / ncg;
     const int o = cg * 16 + n, b = b0 + n;
     const bool ook = o < O, bok = b < B;
-    const float* wr = w + (long)(ook ? o : 0) * K + 4 * kk;
-    const float* xr = x + (long)(bok ? b : 0) * K + 4 * kk;
+    const float* wr = w + (long)(ook ? o : 0) * K;
+    const float* xr = x + (long)(bok ? b : 0) * K;
     const int k0 = slab * slab_len;
     const int k1 = k0 + slab_len < K ? k0 + slab_len : K;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -111,8 +111,10 @@ __global__ __launch_bounds__(256) void linear_fwd_mfma_k(const float* __restrict
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             // clamped, unconditional loads (no branch for the compiler to wait at); masked where used
-            const int k = kb + 16 * u;
-            kok[u] = k + 4 * kk < k1;
+            // a masked lane re-reads the slab's first four elements (k0 is a multiple of 4 below K and K is a
+            // multiple of 4, so those always lie inside the row -- nothing is read past the end of a row)
+            const int k = kb + 16 * u + 4 * kk;
+            kok[u] = k < k1;
             const int kc = kok[u] ? k : k0;
             wv[u] = *reinterpret_cast<const float4*>(wr + kc);
             xv[u] = *reinterpret_cast<const float4*>(xr + kc);

@@ -42,11 +42,15 @@ int conv_path() {
 // siv_pack_cache_invalidate.  A slot is filled by the stream of the call that created it; later calls on
 // the same stream read it in order.
 namespace {
+struct PackSlot {
+    size_t off;
+    bool valid;       // false: the weights changed since the slot was filled (the slot keeps its memory)
+};
 struct PackCache {
     char* base = nullptr;
     size_t size = 0, used = 0;
     std::vector<std::pair<const char*, const char*>> stable;      // [lo, hi) ranges of cacheable weights
-    std::map<std::tuple<const void*, int, int, int, int, int>, size_t> slots;
+    std::map<std::tuple<const void*, int, int, int, int, int>, PackSlot> slots;
     long hits = 0, misses = 0;
 };
 constexpr int kMaxDevices = 64;
@@ -71,17 +75,33 @@ void* pack_slot(const void* w, int family, int variant, int flip, int Cin, int C
     const auto key = std::make_tuple(w, family, variant, flip, Cin, Cout);
     auto it = c->slots.find(key);
     if (it != c->slots.end()) {
-        *need_pack = false;
-        ++c->hits;
-        return c->base + it->second;
+        if (it->second.valid) {
+            *need_pack = false;
+            ++c->hits;
+        } else {
+            it->second.valid = true;       // refilled in place by the caller (same key = same size)
+            ++c->misses;
+        }
+        return c->base + it->second.off;
     }
     const size_t need = align256(bytes);
     if (c->used + need > c->size) return ws;                      // cache full: pack into the workspace as before
     const size_t off = c->used;
     c->used += need;
-    c->slots.emplace(key, off);
+    c->slots.emplace(key, PackSlot{off, true});
     ++c->misses;
     return c->base + off;
+}
+
+void pack_slot_failed(const void* slot) {
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    PackCache* c = current_cache();
+    if (!c || !c->base) return;
+    for (auto& kv : c->slots)
+        if (c->base + kv.second.off == (const char*)slot) {
+            kv.second.valid = false;
+            return;
+        }
 }
 
 // conv_generic.hip
@@ -232,7 +252,7 @@ using namespace siv;
 
 extern "C" const char* siv_last_error(void) { return g_err; }
 extern "C" const char* siv_last_conv_kernel(void) { return g_conv_kernel; }
-extern "C" int siv_version(void) { return 106; }
+extern "C" int siv_version(void) { return 107; }
 extern "C" size_t siv_workspace_bytes(void) { return (size_t)512 << 20; }
 extern "C" int siv_pack_cache_configure(void* mem, size_t bytes) {
     SIV_CHECK_ARG(((uintptr_t)mem & 255) == 0, "pack_cache_configure: memory must be 256-byte aligned");
@@ -269,6 +289,16 @@ extern "C" int siv_pack_cache_invalidate(void) {
     std::lock_guard<std::mutex> lock(g_pack_mu);
     PackCache* c = current_cache();
     if (c) c->slots.clear(), c->used = 0;
+    return SIV_OK;
+}
+extern "C" int siv_pack_cache_invalidate_range(const void* lo, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_pack_mu);
+    PackCache* c = current_cache();
+    if (!c) return SIV_OK;
+    for (auto& kv : c->slots) {
+        const char* w = (const char*)std::get<0>(kv.first);
+        if (w >= (const char*)lo && w < (const char*)lo + bytes) kv.second.valid = false;
+    }
     return SIV_OK;
 }
 extern "C" long siv_pack_cache_hits(void) {
@@ -354,13 +384,15 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
         case B3: rc = k3_fwd_wino_b3_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part); break;
         case W2D: {
             // the partial outputs of a split channel contraction go behind the statistics rows; a workspace
-            // without room for them (the rows are then those of the unsplit launch, no more than 256) runs unsplit
+            // without room for them runs unsplit, and the unsplit launch writes one statistics row per brick
+            // (which can be more rows than the split launch's: checked again)
             const size_t used = wbytes + (size_t)nblk * 2 * Cout * sizeof(float);
             void* kws = ws_tail(ws, ws_bytes, used);
             size_t kbytes = ws_tail_bytes(ws_bytes, used);
             if (kbytes < k3_fwd_wino2d_ksplit_bytes(N, D, H, W, Cin, Cout)) {
                 kws = nullptr, kbytes = 0;
                 nblk = k3_fwd_wino2d_bricks(N, D, H, W);
+                SIV_CHECK_WS(wbytes + (size_t)nblk * 2 * Cout * sizeof(float), ws_bytes, "conv3d_k3_fwd_bnstats");
             }
             rc = k3_fwd_wino2d_launch(x, w, bias, y, N, D, H, W, Cin, Cout, 0, ws, ws_bytes, s, part, kws, kbytes);
             break;

@@ -45,6 +45,19 @@ int conv_path();   // 0 auto, 1 generic, 2 specialised
 enum PackFamily { PF_MFMA = 1, PF_WINO, PF_WINO_B3, PF_WINO2D, PF_UP_PROD, PF_UP_B3, PF_UP, PF_UPD_B3, PF_UPD_BOX, PF_UPD };
 void* pack_slot(const void* w, int family, int variant, int flip, int Cin, int Cout, size_t bytes, void* ws,
                 bool* need_pack);
+// A packing kernel that was to fill `slot` did not launch: the cache forgets the slot, so that no later
+// call takes it for a finished packing.
+void pack_slot_failed(const void* slot);
+// to be used right after the launch of a packing kernel whose destination came from pack_slot
+#define SIV_CHECK_PACK_LAUNCH(what, slot)                                                \
+    do {                                                                                 \
+        hipError_t e__ = hipGetLastError();                                              \
+        if (e__ != hipSuccess) {                                                         \
+            siv::pack_slot_failed(slot);                                                 \
+            siv::set_error("%s: launch failed: %s", what, hipGetErrorString(e__));       \
+            return SIV_EHIP;                                                             \
+        }                                                                                \
+    } while (0)
 
 // 16 bytes through a buffer descriptor: byte offset = per-lane voff + wave-uniform soff (+ an immediate the
 // compiler folds).  No 64-bit address arithmetic on the vector ALU, and a lane whose voff lies beyond the

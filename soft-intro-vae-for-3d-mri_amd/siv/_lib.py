@@ -17,6 +17,7 @@ SIGNATURES = {
     "siv_pack_cache_add_weights": [_f, _sz],
     "siv_pack_cache_remove_weights": [_f],
     "siv_pack_cache_invalidate": [],
+    "siv_pack_cache_invalidate_range": [_f, _sz],
     "siv_conv3d_k3_fwd": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_conv3d_k3_fwd_bnstats": [_f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _fl, _f, _sz, _f],
     "siv_conv3d_k3_dgrad": [_f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],

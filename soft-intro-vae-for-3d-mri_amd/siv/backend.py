@@ -106,9 +106,16 @@ class HipBackend:
         except Exception:       # interpreter shutdown
             pass
 
-    def weights_changed(self, device=None) -> None:
-        """Forget every cached packing (called after an optimiser step wrote the weights behind torch's back)."""
+    def weights_changed(self, device=None, flat: Optional[torch.Tensor] = None) -> None:
+        """The weights were written behind torch's back (an optimiser step, a graph replay): forget the cached
+        packings -- all of them, or with ``flat`` (a registered flat parameter buffer) only those of the
+        weights inside it, so that an encoder update leaves the decoder's packings valid and vice versa."""
         if not self._pack_cache:
+            return
+        if flat is not None:
+            if flat.device in self._pack_cache:
+                with torch.cuda.device(flat.device):
+                    self.lib.siv_pack_cache_invalidate_range(flat.data_ptr(), flat.numel() * flat.element_size())
             return
         for dev in ([device] if device is not None else list(self._pack_cache)):
             if dev in self._pack_cache:

@@ -118,7 +118,7 @@ class FlatAdam:
             B.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.lr, self.betas[0],
                         self.betas[1], self.eps, self.step_count)
         if hasattr(B, "weights_changed"):
-            B.weights_changed(self.flat_p.device)
+            B.weights_changed(self.flat_p.device, self.flat_p)    # only this group's packed weights are stale
 
 
 class MultiStepLR:

@@ -7,9 +7,11 @@ dim 0, BatchNorm statistics are per replica (no SyncBN), every loss term is a ba
 the average of the rank gradients equals the full-batch gradient.  Each optimiser step
 needs exactly one exchange: sum the rank gradients, divide by the world size.
 
-The all-reduce runs on a side HIP stream so that the (tiny, 28.5 MB) exchange of one
-buffer can overlap whatever the main stream still has queued; the optimiser waits on an
-event, never on the host.
+The all-reduce and the optimiser update that consumes it run on a side HIP stream, so that the
+(tiny, 28.5 MB) exchange overlaps main-stream work that does not read the weights being updated:
+the encoder exchange + update hide behind the D-step's first two decoder passes, the decoder
+exchange + update behind the NEXT iteration's ``encode(real)``; the main stream waits on an event,
+never on the host.  ``SIV_DP_OVERLAP=0`` runs everything in order on the main stream instead.
 """
 from __future__ import annotations
 
@@ -57,9 +59,15 @@ class GradSync:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.side = None
         self.collective = self.world > 1 or (_forced() and dist.is_initialized())
+        self.overlap = os.environ.get("SIV_DP_OVERLAP", "1") != "0"
         if self.collective and device is not None and torch.device(device).type == "cuda":
             self.side = torch.cuda.Stream(device=device)
         self._pending = None           # event recorded on the side stream behind an exchange + step
+
+    @property
+    def pending(self) -> bool:
+        """True while an exchange + update issued on the side stream has not been joined by ``wait()``."""
+        return self._pending is not None
 
     def shard(self, batch: torch.Tensor) -> torch.Tensor:
         """Rank r's slice [r*B/W, (r+1)*B/W) of a global batch."""
@@ -113,16 +121,40 @@ class GradSync:
         that does not read the parameters of ``opt`` (the D-step's first two decoder passes after the
         encoder update) overlaps the exchange and the update.  ``wait()`` must be called before the
         updated parameters, or the gradient buffer, are touched again."""
-        if not self.collective or self.side is None:
+        if not self.collective or self.side is None or not self.overlap:
             self.average_(opt.flat_g)
             opt.step()
             return
+        self.wait()                    # one exchange in flight at a time (the side stream is ordered anyway)
         main = torch.cuda.current_stream(opt.flat_g.device)
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             self._exchange(opt.flat_g)
             opt.step()
             self._pending = self.side.record_event()
+
+    def finish_step(self, opt, stats: torch.Tensor) -> torch.Tensor:
+        """End of an iteration: the logged statistics become means over the global batch, ``opt.flat_g`` is
+        averaged and ``opt.step()`` runs.  On a GPU job all three go to the side stream -- statistics first,
+        and the main stream waits for those only; the exchange + update stay in flight (``pending``) until
+        the next ``wait()``, which the caller places in front of the next use of ``opt``'s parameters."""
+        if not self.collective or self.side is None or not self.overlap:
+            self.average_(opt.flat_g)
+            opt.step()
+            return self.average_stats_(stats)
+        self.wait()
+        main = torch.cuda.current_stream(stats.device)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+            get_backend().scale_(stats, 1.0 / self.world)
+            have_stats = self.side.record_event()
+            self._exchange(opt.flat_g)
+            opt.step()
+            self._pending = self.side.record_event()
+        stats.record_stream(self.side)
+        main.wait_event(have_stats)
+        return stats
 
     def wait(self) -> None:
         if self._pending is not None:

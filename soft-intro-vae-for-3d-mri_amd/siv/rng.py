@@ -34,18 +34,22 @@ class PhiloxKeep:
 
 
 class DeviceRng:
-    """Philox-4x32-10 on the device; call ``i`` of rank ``r`` uses stream id (r << 40) | i."""
+    """Philox-4x32-10 on the device; call ``i`` of rank ``r`` uses stream id (r << 40) | i, with bit 39 set
+    for the draws of a captured HIP graph: a graph replays the same call indices every time (only the epoch
+    counter moves), so its ids live in a namespace of their own that no eager draw can land in."""
 
     EPOCH_STRIDE = 1 << 20      # stream ids of epoch e start at e * 2^20 (SIV_EPOCH_STRIDE of the kernels)
+    GRAPH_NS = 1 << 39          # stream ids of draws captured in a HIP graph carry this bit; eager draws never do
 
     def __init__(self, seed: int = 0, rank: int = 0):
         self.seed = int(seed)
         self.rank = int(rank)
         self.calls = 0
+        self.ns = 0             # 0, or GRAPH_NS while a HIP graph is being captured
         self.epoch = None       # device int64 counter, present once use_device_epoch() was called
 
     def _sid(self) -> int:
-        sid = (self.rank << 40) | self.calls
+        sid = (self.rank << 40) | self.ns | self.calls
         self.calls += 1
         return sid
 

@@ -109,6 +109,38 @@ class SoftIntroStep:
         self.beta_rec, self.beta_neg, self.beta_kl, self.gamma_r = beta_rec, beta_neg, beta_kl, gamma_r
         self.scale = scale
         self.sync = sync if sync is not None else GradSync(None)
+        self._dec_draws = None        # random draws one decoder pass makes (known after the first one)
+
+    def flush(self) -> None:
+        """Join a decoder update that a data-parallel job still has in flight (call before anything but the
+        next iteration reads the decoder's parameters: validation, checkpoints)."""
+        self.sync.wait()
+
+    def _first_two_passes(self, model, real_batch, noise_batch):
+        """``fake = decode(noise)`` then ``encode(real)`` (:248-250).  While the previous iteration's decoder
+        exchange + update is still in flight on the side stream, the encoder pass -- which reads no decoder
+        parameter -- is issued first and the decoder pass behind the join.  The device generator keys every
+        draw by its call index, so the two passes keep the indices of the reference order."""
+        r = rng.get_rng()
+        if self.sync.pending and self._dec_draws is not None and isinstance(r, rng.DeviceRng):
+            base = r.calls
+            r.calls = base + self._dec_draws                 # the decoder pass's draws come first in call order
+            real_mu, real_logvar = model.encode(real_batch)
+            after = r.calls
+            r.calls = base
+            self.sync.wait()
+            fake = model.decode(noise_batch)
+            if r.calls != base + self._dec_draws:
+                raise RuntimeError("a decoder pass changed its number of random draws between iterations")
+            r.calls = after
+            return fake, real_mu, real_logvar
+        self.sync.wait()
+        c0 = getattr(r, "calls", None)
+        fake = model.decode(noise_batch)
+        if c0 is not None:
+            self._dec_draws = r.calls - c0
+        real_mu, real_logvar = model.encode(real_batch)
+        return fake, real_mu, real_logvar
 
     def __call__(self, real_batch, noise_batch):
         model = self.model
@@ -120,8 +152,7 @@ class SoftIntroStep:
             p.requires_grad = True
         for p in model.decoder.parameters():
             p.requires_grad = False
-        fake = model.decode(noise_batch)
-        real_mu, real_logvar = model.encode(real_batch)
+        fake, real_mu, real_logvar = self._first_two_passes(model, real_batch, noise_batch)
         z = model.reparameterize(real_mu, real_logvar)
         rec = model.decode(z)
         rec_mu, rec_logvar, z_rec, rec_rec = model.forward(rec.detach())
@@ -158,11 +189,11 @@ class SoftIntroStep:
             ops.sse_per_sample(fake.detach(), rec_fake), scale, br, bk, gr)
         self.opt_d.zero_grad()
         lossD.backward()
-        self.sync.average_and_step(self.opt_d)
-        self.sync.wait()
         fake_kl, rec_kl, loss_rec = sd[0], sd[1], sd[2]
-        # one device->host copy serves every statistic the trainer logs
-        return self.sync.average_stats_(
+        # one device->host copy serves every statistic the trainer logs; on a data-parallel job the decoder
+        # exchange + update stay in flight behind it and are joined by the next iteration (or flush())
+        return self.sync.finish_step(
+            self.opt_d,
             torch.stack([stats_e[0], lossD.detach(), stats_e[1], fake_kl, rec_kl, loss_rec, stats_e[2], stats_e[3]]))
 
 
@@ -185,6 +216,9 @@ class GraphedSoftIntroStep:
             raise ValueError("graph capture needs the device random generator (siv.rng.DeviceRng)")
         if step.sync.collective:
             raise ValueError("graph capture is single-rank: the gradient exchange is not captured")
+        if warmup < 1:
+            raise ValueError("graph capture needs at least one warm-up iteration (lazy allocations, and the "
+                             "packed-weight cache must be empty when the capture starts)")
         self.step, self.rng = step, r
         device = torch.device(device)
         r.use_device_epoch(device)
@@ -196,6 +230,7 @@ class GraphedSoftIntroStep:
         saved_sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
         saved_opt = [(o.m.clone(), o.v.clone(), o.step_count) for o in opts]
         saved_calls = r.calls
+        r.ns = rng.DeviceRng.GRAPH_NS                     # the graph's draws: a stream-id namespace of their own
         cur = torch.cuda.current_stream(device)
         side = torch.cuda.Stream(device=device)
         side.wait_stream(cur)
@@ -203,7 +238,13 @@ class GraphedSoftIntroStep:
             for _ in range(warmup):
                 step(self.real, self.noise)
         cur.wait_stream(side)
-        self.sid_base = r.calls                           # stream ids baked into the graph start here
+        self.sid_base = r.calls                           # stream ids baked into the graph start here (+ GRAPH_NS)
+        from ..backend import get_backend
+        B = get_backend()
+        if hasattr(B, "weights_changed"):
+            # every packed weight is packed INSIDE the graph: a packing that was cached while the capture ran
+            # would be missing from the replays, which update the weights themselves
+            B.weights_changed(device)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = step(self.real, self.noise)
@@ -219,6 +260,9 @@ class GraphedSoftIntroStep:
                 o.dev_step.fill_(n)
             r.epoch.zero_()
         r.calls = saved_calls
+        r.ns = 0
+        if hasattr(B, "weights_changed"):
+            B.weights_changed(device)                     # the weights were just restored
         self.replays = 0
 
     def __call__(self, real_batch, noise_batch):
@@ -326,6 +370,7 @@ def train_soft_intro_vae(
             train_run_kl += st["rec_kl"]
             train_run_loss += st["loss_rec"] + st["rec_kl"]
 
+        step.flush()
         train_lossE /= len(train_loader)                                  # :348 (never reset: quirk kept)
         train_lossD /= len(train_loader)
         train_lossE_list.append(train_lossE)

@@ -101,6 +101,7 @@ def train_soft_intro_vae(
             batch_kls_rec.append(st["rec_kl"])
             batch_rec_errs.append(st["loss_rec"])
 
+        step.flush()
         train_lossE /= len(train_loader)                                  # :317 (never reset: quirk kept)
         train_lossD /= len(train_loader)
         train_lossE_list.append(train_lossE)

@@ -97,6 +97,11 @@ def _worker(rank, world, port, out):
 
 class _NoSync:
     world, rank = 1, 0
+    pending = False
+
+    def finish_step(self, opt, stats):
+        self.average_and_step(opt)
+        return stats
 
     def average_(self, flat_g):
         pass

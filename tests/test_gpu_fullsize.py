@@ -88,53 +88,29 @@ Z1200 = (64, [[64, 1, 2], [128, 1, 2], [256, 2, 2]])       # z-1200main.py:158
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def test_z1200_step_at_full_size_matches_reference():
-    """One E-step + D-step of the benchmark model at the benchmark volume size, batch 1, against
+ADD_TOL = 2e-3       # additive term of the end-to-end gradient bound, of the tensor's maximum
 
-    * fixture g11 (tools/make_goldens.py::g11_fullstep): the REFERENCE's own modules run once in fp32 and once
-      in float64 on the same weights, inputs and draws.  At this size the reference's fp32 gradients sit
-      1e-3..1e-2 of their maximum away from the float64 value of the same formulas (BatchNorm cancellation
-      over 614 400 voxels at batch 1, ~10^8 LeakyReLU kinks, Adam's sign-like update between the E-step and
-      the D-step), so two correct fp32 implementations agree only to that level.  The fixture records that
-      distance e32 per parameter (5e-4..6e-3 of max for the encoder, up to 1.5e-2 for the decoder, whose
-      gradients are taken after the encoder's update); libsiv must be about as close to the float64 value
-      as the reference is.  Measured on MI355X: libsiv 1e-3..5e-3 (encoder), 3e-4..1.5e-2 (decoder) -- the
-      largest encoder value, 5.0e-3 against the reference's 7e-4, is the first convolution of the 10x12x10
-      residual block, where at batch 1 a channel's BatchNorm spans only 1200 voxels and a single LeakyReLU
-      sign flip moves a gradient element by ~1/1200 of the channel's sum.  Bound:
-          |mine - f64| <= 3 e32 + 5e-3 max|f64|          on the 256 stored elements of every parameter;
-    * the fp32 CPU oracle run on the spot, over ALL elements, with the bound the triangle inequality gives:
-          |mine - oracle| <= 3 e32 + 5e-3 max + 2 e32;
-      (every kernel on the path is pinned at 1e-4 at these very shapes by the test above)
-    * E-step scalars (computed before any update) at 1e-4 against the reference AND the oracle; D-step KL
-      terms, which depend on the updated encoder, by the same as-good-as-the-reference rule;
-    * weights after both Adam updates and BatchNorm running statistics against the oracle."""
+
+def _fullsize_setup(gen_seed):
     import siv.models.models as models
-    import siv.rng as srng
     import siv.utils.my_trainer as trainer
-    from siv.optim import FlatAdam
-    g = np.load(os.path.join(GOLDEN, "g11_fullstep.npz"), allow_pickle=False)
     torch.manual_seed(82)
     net = models.SoftIntroVAE(*Z1200)
     torch.manual_seed(77)
     net.apply(trainer.init_weights_he)
-    gen = torch.Generator().manual_seed(int(g["data_seed"]))
+    gen = torch.Generator().manual_seed(gen_seed)
     with torch.no_grad():          # BN affine parameters away from (1, 0) so their gradients matter
         for m in net.modules():
             if isinstance(m, torch.nn.BatchNorm3d):
                 m.weight.copy_(1 + 0.2 * torch.randn(m.weight.shape, generator=gen))
                 m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
-    sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    for k, v in sd0.items():       # the very weights the fixture was computed on
-        assert abs(float(v.double().sum()) - float(g["sd0sum." + k])) <= 1e-9 * (1 + abs(float(g["sd0sum." + k]))), k
-    sd = {k: v.detach().clone() for k, v in sd0.items()}
-    real = torch.rand(1, 1, *V0, generator=gen)
-    noise = torch.randn(1, 1, *V3, generator=gen)
-    hp = O.Hyper(beta_rec=float(g["hp.beta_rec"]), beta_neg=float(g["hp.beta_neg"]), beta_kl=float(g["hp.beta_kl"]),
-                 gamma_r=float(g["hp.gamma_r"]), scale=float(g["hp.scale"]))
-    seed = int(g["draw_seed"])
-    ref = O.soft_intro_step(sd, O.Cfg(*Z1200), real, noise, O.Draws(seed=seed), hp, {}, {})
+    return net, gen
 
+
+def _run_libsiv_step(net, real, noise, hp, seed):
+    import siv.rng as srng
+    import siv.utils.my_trainer as trainer
+    from siv.optim import FlatAdam
     net = net.to("cuda").train()
     opt_e = FlatAdam(net.encoder.parameters(), lr=hp.lr)
     opt_d = FlatAdam(net.decoder.parameters(), lr=hp.lr)
@@ -147,6 +123,60 @@ def test_z1200_step_at_full_size_matches_reference():
                                         for k, p in net.decoder.named_parameters()}), od())
     with srng.use_rng(srng.ReplayRng(O.Draws(seed=seed))):
         st = dict(zip(trainer.STAT_NAMES, step(real.cuda(), noise.cuda()).cpu().tolist()))
+    return net, grads, st
+
+
+CANCELLED = ("encoder.blocks.0.0.bias", "decoder.blocks.0.0.bias", "decoder.blocks.0.0.weight")
+
+
+def _check_state_after_step(net, sd, ref, hp):
+    for k, v in net.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(sd[k]), k
+        elif k.endswith(("running_mean", "running_var")):
+            check_max(v, sd[k], k, tol=2e-3, floor=5e-4)
+        elif not k.endswith(CANCELLED):
+            rg = ref["gradE" if k.startswith("encoder.") else "gradD"][k]
+            check_params_after_adam(v, sd[k], rg, hp.lr, k)
+
+
+def test_z1200_step_at_full_size_matches_reference():
+    """One E-step + D-step of the benchmark model at the benchmark volume size, batch 1, against
+
+    * fixture g11 (tools/make_goldens.py::g11_fullstep): the REFERENCE's own modules run once in fp32 and once
+      in float64 on the same weights, inputs and draws.  At this size the reference's fp32 gradients sit
+      1e-3..1e-2 of their maximum away from the float64 value of the same formulas (BatchNorm cancellation
+      over 614 400 voxels at batch 1, ~10^8 LeakyReLU kinks, Adam's sign-like update between the E-step and
+      the D-step), so two correct fp32 implementations agree only to that level.  The fixture records that
+      distance e32 per parameter (5e-4..6e-3 of max for the encoder, up to 1.5e-2 for the decoder, whose
+      gradients are taken after the encoder's update); libsiv must be about as close to the float64 value
+      as the reference is.  Measured on MI355X with tools/diag_fullstep.py, per parameter, of the tensor's
+      maximum from float64: the automatic dispatch (Winograd kernels) 5e-4..8e-3 for the encoder and
+      3e-4..1.6e-2 for the decoder; the DIRECT matrix-core kernels (conv path 4, which add in the oracle's
+      order) 7e-4..1.5e-2 and 2e-4..1.7e-2; the fp32 oracle itself 4e-4..6e-3 and 2e-4..9e-3.  The Winograd
+      kernels are no further from the truth than the direct ones: the distance is the LeakyReLU / BatchNorm
+      sensitivity of the network in fp32, not a property of a kernel family.  Ratio libsiv / oracle per
+      parameter: at most 2.4.  Bound:
+          |mine - f64| <= 3 e32 + ADD_TOL max|f64|       on the 256 stored elements of every parameter;
+    * the fp32 CPU oracle run on the spot, over ALL elements, with the bound the triangle inequality gives:
+          |mine - oracle| <= 3 e32 + ADD_TOL max + 2 e32;
+      (every kernel on the path is pinned at 1e-4 at these very shapes by the test above)
+    * E-step scalars (computed before any update) at 1e-4 against the reference AND the oracle; D-step KL
+      terms, which depend on the updated encoder, by the same as-good-as-the-reference rule;
+    * weights after both Adam updates and BatchNorm running statistics against the oracle."""
+    g = np.load(os.path.join(GOLDEN, "g11_fullstep.npz"), allow_pickle=False)
+    net, gen = _fullsize_setup(int(g["data_seed"]))
+    sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    for k, v in sd0.items():       # the very weights the fixture was computed on
+        assert abs(float(v.double().sum()) - float(g["sd0sum." + k])) <= 1e-9 * (1 + abs(float(g["sd0sum." + k]))), k
+    sd = {k: v.detach().clone() for k, v in sd0.items()}
+    real = torch.rand(1, 1, *V0, generator=gen)
+    noise = torch.randn(1, 1, *V3, generator=gen)
+    hp = O.Hyper(beta_rec=float(g["hp.beta_rec"]), beta_neg=float(g["hp.beta_neg"]), beta_kl=float(g["hp.beta_kl"]),
+                 gamma_r=float(g["hp.gamma_r"]), scale=float(g["hp.scale"]))
+    seed = int(g["draw_seed"])
+    ref = O.soft_intro_step(sd, O.Cfg(*Z1200), real, noise, O.Draws(seed=seed), hp, {}, {})
+    net, grads, st = _run_libsiv_step(net, real, noise, hp, seed)
 
     for mine, r in (("lossE", "lossE"), ("kl_real", "kl_real"), ("loss_rec", "loss_rec_D")):
         np.testing.assert_allclose(st[mine], float(g["f32." + r]), rtol=1e-4, err_msg=mine + " vs reference")
@@ -163,7 +193,6 @@ def test_z1200_step_at_full_size_matches_reference():
         else:
             assert st[mine] < 1e-40, mine
 
-    cancelled = ("encoder.blocks.0.0.bias", "decoder.blocks.0.0.bias", "decoder.blocks.0.0.weight")
     worst = (0.0, "")
     for k, gr in grads.items():
         which = "gradE" if k.startswith("encoder.") else "gradD"
@@ -172,10 +201,10 @@ def test_z1200_step_at_full_size_matches_reference():
         if key + ".none" in g.files:
             assert rg is None and float(gr.abs().max()) == 0.0, k
             continue
-        if k.endswith(cancelled):                           # BN cancels these gradients to rounding noise
+        if k.endswith(CANCELLED):                           # BN cancels these gradients to rounding noise
             continue
         mx, e32 = float(g[key + ".max"]), float(g[key + ".err32"])
-        lim = 3 * e32 + 5e-3 * mx
+        lim = 3 * e32 + ADD_TOL * mx
         idx = torch.from_numpy(g[key + ".idx"])
         mine_s = gr.reshape(-1)[idx].double().numpy()
         err_t = float(np.abs(mine_s - g[key + ".t64"]).max())
@@ -187,14 +216,61 @@ def test_z1200_step_at_full_size_matches_reference():
         if err_t / lim > worst[0]:
             worst = (err_t / lim, k)
     print(f"z=1200 full-size step: worst error / bound = {worst[0]:.2f} at {worst[1]}")
-    for k, v in net.state_dict().items():
-        if k.endswith("num_batches_tracked"):
-            assert int(v) == int(sd[k]), k
-        elif k.endswith(("running_mean", "running_var")):
-            check_max(v, sd[k], k, tol=2e-3, floor=5e-4)
-        elif not k.endswith(cancelled):
-            rg = ref["gradE" if k.startswith("encoder.") else "gradD"][k]
-            check_params_after_adam(v, sd[k], rg, hp.lr, k)
+    _check_state_after_step(net, sd, ref, hp)
+
+
+def test_z1200_step_at_full_size_batch2_matches_oracle():
+    """The same iteration at batch 2 (BatchNorm statistics over two samples, batch means of two per-sample
+    terms, the shapes the benchmark's batch 8 runs per sample) against the oracle computed on the spot twice:
+    in fp32 and in float64 (the oracle is pinned to the reference by the fixtures at 1e-5).  The float64 run is
+    the truth, the fp32 run measures how far a correct fp32 implementation lands from it (e32 per parameter),
+    and libsiv is held to  |mine - f64| <= 3 e32 + ADD_TOL max|f64|  over ALL elements of every parameter
+    gradient; E-step scalars at 1e-4; D-step KL terms by the as-good-as-fp32 rule; weights after both Adam
+    updates and BatchNorm running statistics against the fp32 oracle."""
+    Bn, seed = 2, 43
+
+    class Draws64(O.Draws):
+        def _emit(self, shape, make):
+            return super()._emit(shape, make).double()
+
+    net, gen = _fullsize_setup(105)
+    sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    real = torch.rand(Bn, 1, *V0, generator=gen)
+    noise = torch.randn(Bn, 1, *V3, generator=gen)
+    hp = O.Hyper(dims=V0)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    ref = O.soft_intro_step(sd, O.Cfg(*Z1200), real, noise, O.Draws(seed=seed), hp, {}, {})
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    tru = O.soft_intro_step(sd64, O.Cfg(*Z1200), real.double(), noise.double(), Draws64(seed=seed), hp, {}, {})
+    del sd64
+    net, grads, st = _run_libsiv_step(net, real, noise, hp, seed)
+
+    for mine, r in (("lossE", "lossE"), ("kl_real", "kl_real"), ("loss_rec", "loss_rec_D")):
+        np.testing.assert_allclose(st[mine], float(tru[r]), rtol=1e-4, err_msg=mine + " vs float64 oracle")
+        np.testing.assert_allclose(st[mine], float(ref[r]), rtol=1e-4, err_msg=mine + " vs fp32 oracle")
+    for mine, r in (("lossD", "lossD"), ("fake_kl", "fake_kl"), ("rec_kl", "rec_kl")):
+        f32, f64 = float(ref[r]), float(tru[r])
+        lim = max(3 * abs(f32 - f64), 1e-3 * abs(f64))
+        assert abs(st[mine] - f64) <= lim, (mine, st[mine], f32, f64)
+    worst = (0.0, "")
+    for k, gr in grads.items():
+        which = "gradE" if k.startswith("encoder.") else "gradD"
+        rg, tg = ref[which][k], tru[which][k]
+        if rg is None:
+            assert float(gr.abs().max()) == 0.0, k
+            continue
+        if k.endswith(CANCELLED):
+            continue
+        mx = float(tg.abs().max())
+        e32 = float((rg.double() - tg).abs().max())
+        err_t = float((gr.double() - tg).abs().max())
+        lim = 3 * e32 + ADD_TOL * mx
+        print(f"{k:44s} from f64 {err_t / mx:.2e} (fp32 oracle {e32 / mx:.2e})")
+        assert err_t <= lim + 1e-7, f"{k}: {err_t / mx:.2e} of max from float64 (fp32 oracle: {e32 / mx:.2e})"
+        if err_t / lim > worst[0]:
+            worst = (err_t / lim, k)
+    print(f"z=1200 full-size step, batch {Bn}: worst error / bound = {worst[0]:.2f} at {worst[1]}")
+    _check_state_after_step(net, sd, ref, hp)
 
 
 def test_full_resolution_160_model_matches_oracle():
@@ -242,3 +318,94 @@ def test_full_resolution_160_model_matches_oracle():
     assert all(np.isfinite(v) for v in st.values()), st
     moved = float(((opt_e.flat_p - w0).abs() > 0).float().mean())
     assert moved > 0.9, moved
+
+
+def test_config4_160_flip_shift_bf16_storage_step_matches_oracle():
+    """The workload of the 160x192x160 configuration on one GPU, all of its pieces together: raw volume ->
+    ``DeviceLoader(..., augment=FlipShift)`` (pinned copy, flip / shift, clip + min-max on the device) ->
+    ``soft_intro_vae_z1200(full_resolution=True)`` (the z=1200 stack with one more stride-2 stage; the reference
+    builds 80x96x80 models only, aug-z-1200main.py:106-119 is where its augmentation sits) -> one E-step +
+    D-step at batch 1 with the saved activations stored as bf16 (``activations.storage("bf16")``), replayed
+    random draws.  Checked:
+    * the loader's output against the oracle's definition of the same flip / shift and ``_preprocess``
+      (utils/data_load.py:25-30) at 1e-4 of the [0, 1] output range;
+    * the iteration against ``O.soft_intro_step`` (fp32 CPU oracle) on that very input, at the tolerance the bf16
+      storage mode states: scalars at 1e-2, every parameter gradient within 6e-2 of its tensor's maximum
+      (E-step scalars, which are forward arithmetic on the initial weights, at 1e-4: the forward pass of the
+      storage mode is fp32);
+    * that the mode was on (saved tensors packed) and that BatchNorm's running statistics match."""
+    import siv.activations as act
+    import siv.models.models as models
+    import siv.rng as srng
+    import siv.utils.my_trainer as trainer
+    from siv.optim import FlatAdam
+    from siv.utils.data_load import BrainDataset, DeviceLoader, FlipShift
+    dims, seed = (160, 192, 160), 47
+    rs = np.random.RandomState(8)
+    # a raw "scan": positive intensities inside an ellipsoid, a few outliers above 4 sigma for the clip to cut
+    zz, yy, xx = np.meshgrid(*(np.linspace(-1, 1, d, dtype=np.float32) for d in dims), indexing="ij")
+    raw = (np.abs(rs.randn(*dims).astype(np.float32)) * 300 + 100) * ((zz / 0.84) ** 2 + (yy / 0.84) ** 2 + (xx / 0.84) ** 2 < 1)
+    raw.reshape(-1)[rs.choice(raw.size, 2000, replace=False)] = 5000.0
+    ds = BrainDataset([raw], [0])
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
+    aug = FlipShift(p_flip=(0.0, 0.0, 1.0), max_shift=(4, 4, 4), seed=5)
+    params = FlipShift(p_flip=(0.0, 0.0, 1.0), max_shift=(4, 4, 4), seed=5).draw(1)[0].tolist()   # the same draw
+    (real_dev, _), = list(DeviceLoader(loader, "cuda", augment=aug))
+    want = O.preprocess(O.flip_shift(raw, params[:3], params[3:]))
+    assert params[2] == 1 and tuple(real_dev.shape) == (1, 1) + dims
+    np.testing.assert_allclose(real_dev.cpu().numpy()[0], want, rtol=0, atol=1e-4)
+    real = real_dev.cpu().contiguous()
+    del raw, zz, yy, xx, want
+
+    torch.manual_seed(82)
+    net = models.soft_intro_vae_z1200(full_resolution=True)
+    torch.manual_seed(77)
+    net.apply(trainer.init_weights_he)
+    gen = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.weight.copy_(1 + 0.2 * torch.randn(m.weight.shape, generator=gen))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+    noise = torch.randn(1, 1, *V3, generator=gen)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    cfg, hp = O.Cfg(64, models.BLOCKS_Z1200_160), O.Hyper(dims=dims)
+    ref = O.soft_intro_step(sd, cfg, real, noise, O.Draws(seed=seed), hp, {}, {})
+
+    net = net.to("cuda").train()
+    opt_e, opt_d = FlatAdam(net.encoder.parameters(), lr=hp.lr), FlatAdam(net.decoder.parameters(), lr=hp.lr)
+    step = trainer.SoftIntroStep(net, opt_e, opt_d, hp.beta_rec, hp.beta_neg, hp.beta_kl, hp.gamma_r, hp.scale)
+    grads = {}
+    oe, od = opt_e.step, opt_d.step
+    opt_e.step = lambda: (grads.update({"encoder." + k: p.grad.detach().clone().cpu()
+                                        for k, p in net.encoder.named_parameters()}), oe())
+    opt_d.step = lambda: (grads.update({"decoder." + k: p.grad.detach().clone().cpu()
+                                        for k, p in net.decoder.named_parameters()}), od())
+    before = dict(act.packed)
+    try:
+        with act.storage("bf16"), srng.use_rng(srng.ReplayRng(O.Draws(seed=seed))):
+            st = dict(zip(trainer.STAT_NAMES, step(real_dev, noise.cuda()).cpu().tolist()))
+    finally:
+        act.set_storage("fp32")
+    assert act.packed["tensors"] - before["tensors"] >= 60       # 13 passes x the large saved tensors of 4 stages
+    for mine, r in (("lossE", "lossE"), ("kl_real", "kl_real")):
+        np.testing.assert_allclose(st[mine], float(ref[r]), rtol=1e-4, err_msg=mine)
+    for mine, r in (("lossD", "lossD"), ("fake_kl", "fake_kl"), ("rec_kl", "rec_kl"), ("loss_rec", "loss_rec_D")):
+        np.testing.assert_allclose(st[mine], float(ref[r]), rtol=1e-2, err_msg=mine)
+    worst = (0.0, "")
+    for k, gr in grads.items():
+        rg = ref["gradE" if k.startswith("encoder.") else "gradD"][k]
+        if rg is None:
+            assert float(gr.abs().max()) == 0.0, k
+            continue
+        if k.endswith(CANCELLED):
+            continue
+        m = float(rg.abs().max()) + 1e-30
+        err = float((gr - rg).abs().max()) / m
+        assert err <= 6e-2, f"{k}: {err:.2e} of max away from the fp32 oracle"
+        if err > worst[0]:
+            worst = (err, k)
+    for k, v in net.state_dict().items():
+        if k.endswith(("running_mean", "running_var")):
+            check_max(v, sd[k], k, tol=2e-3, floor=5e-4)
+    print(f"160x192x160 + flip/shift + bf16 storage, batch 1: worst gradient error {worst[0]:.2e} of max at {worst[1]}")

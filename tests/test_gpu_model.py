@@ -637,10 +637,25 @@ def test_graphed_step_matches_eager_step():
         out_g.append(g(real, noise).clone())
         sd_g.append({k: v.detach().clone() for k, v in net_g.state_dict().items()})
     assert oe_g.step_count == 2 and int(oe_g.dev_step) == 2 and int(srng.get_rng().epoch) == 2
+    # eager draws (the per-iteration latent noise) can never meet a draw baked into the graph: the graph's
+    # stream ids carry DeviceRng.GRAPH_NS, eager ids stay below it however many iterations have run
+    rg = srng.get_rng()
+    assert rg.ns == 0 and g.sid_base > 0
+    for calls, epoch in ((0, 0), (g.sid_base, 1), (3 * g.sid_base + 5, 3 * g.sid_base + 5), (1 << 19, 1 << 18)):
+        rg_calls, rg.calls = rg.calls, calls
+        eager_id = rg._sid() + epoch * srng.DeviceRng.EPOCH_STRIDE
+        rg.calls = rg_calls
+        assert eager_id < srng.DeviceRng.GRAPH_NS
+    import siv.backend as sb
+    span = 64
+    e_eager = sb.get_backend().randn((4, 16), "cuda", 9, g.sid_base + 3, None)
+    e_graph = sb.get_backend().randn((4, 16), "cuda", 9, srng.DeviceRng.GRAPH_NS | (g.sid_base + 3), None)
+    assert not torch.equal(e_eager, e_graph) and span > 0
 
     net_e, oe_e, od_e, step_e = build()
     r = srng.DeviceRng(9, 0)
     srng.set_rng(r)
+    r.ns = srng.DeviceRng.GRAPH_NS                                       # the graph's stream-id namespace
     for i, (real, noise) in enumerate(batches):
         r.calls = g.sid_base + i * srng.DeviceRng.EPOCH_STRIDE          # the ids the graph uses in replay i
         out = step_e(real, noise)
@@ -693,3 +708,64 @@ def test_side_stream_weight_gradients_match_serial_backward():
     for a, b in zip(s1 + g1 + [pe1, pd1], s0 + g0 + [pe0, pd0]):
         assert torch.equal(a, b)
     assert float(g1[0].abs().max()) > 0 and float(g1[1].abs().max()) > 0
+
+
+def test_data_parallel_side_stream_path_matches_serial_path(monkeypatch):
+    """The multi-GPU path of the iteration on ONE GPU (a one-rank RCCL job forced through the collective code:
+    SIV_FORCE_COLLECTIVE=1): encoder exchange + Adam on the side stream beside the D-step's first two decoder
+    passes, statistics all-reduce + decoder exchange + Adam on the side stream at the end of the iteration and
+    joined by the NEXT iteration behind its encoder pass (which is issued first, with the random call indices
+    of the reference order).  Three iterations against the same three with SIV_DP_OVERLAP=0 (every exchange
+    and update in order on the main stream): statistics, weights, Adam moments and BatchNorm buffers are
+    bit-identical."""
+    import socket
+    import torch.distributed as dist
+    import siv.models.models as models
+    import siv.rng as srng
+    import siv.utils.my_trainer as trainer
+    from siv.optim import FlatAdam
+    from siv.parallel import GradSync
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    for k, v in dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                     SIV_FORCE_COLLECTIVE="1").items():
+        monkeypatch.setenv(k, v)
+    dims, Bn = (16, 24, 16), 2
+    gen = torch.Generator().manual_seed(61)
+    batches = [(torch.rand(Bn, 1, *dims, generator=gen).cuda(), torch.randn(Bn, 1, 4, 6, 4, generator=gen).cuda())
+               for _ in range(3)]
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        def run(overlap):
+            monkeypatch.setenv("SIV_DP_OVERLAP", "1" if overlap else "0")
+            torch.manual_seed(60)
+            net = models.SoftIntroVAE(*WIDE)
+            net.apply(trainer.init_weights_he)
+            net = net.to("cuda").train()
+            sync = GradSync(torch.device("cuda", 0))
+            assert sync.collective and sync.side is not None and sync.overlap == overlap
+            sync.broadcast_(net)
+            oe, od = FlatAdam(net.encoder.parameters(), lr=2e-4), FlatAdam(net.decoder.parameters(), lr=2e-4)
+            step = trainer.SoftIntroStep(net, oe, od, sync=sync)
+            srng.manual_seed(11, 0)
+            outs = []
+            for i, (real, noise) in enumerate(batches):
+                outs.append(step(real, noise).clone())
+                assert sync.pending == overlap        # the decoder update is still in flight / already done
+            step.flush()
+            torch.cuda.synchronize()
+            return outs, {k: v.detach().clone() for k, v in net.state_dict().items()}, \
+                (oe.flat_p.clone(), od.flat_p.clone(), oe.m.clone(), od.m.clone(), oe.v.clone(), od.v.clone()), \
+                srng.get_rng().calls
+        o1, sd1, opt1, calls1 = run(True)
+        o0, sd0, opt0, calls0 = run(False)
+    finally:
+        dist.destroy_process_group()
+    assert calls1 == calls0
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b), (a, b)
+    for k in sd0:
+        assert torch.equal(sd1[k], sd0[k]), k
+    for a, b in zip(opt1, opt0):
+        assert torch.equal(a, b)

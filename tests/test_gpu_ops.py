@@ -472,7 +472,8 @@ def test_axpby(B):
 
 
 @pytest.mark.parametrize("b,k,o", [(2, 1200, 32), (8, 19200, 1200), (8, 600, 19200), (3, 37, 5), (11, 130, 64),
-                                   (17, 68, 21), (4, 19200, 1200), (1, 600, 19200), (5, 4, 3)])
+                                   (17, 68, 21), (4, 19200, 1200), (1, 600, 19200), (5, 4, 3),
+                                   (3, 20, 7), (2, 19204, 16), (2, 76, 33)])  # last K slab shorter than 16
 def test_linear_fwd_dgrad_wgrad(B, b, k, o):
     """nn.Linear of the FC-latent model (models/mymodel.py:125,151) incl. the benchmark shapes
     (B=8: 19200 -> 1200 and 600 -> 19200), ragged shapes on the VALU kernels (K not a multiple of 4) and on
