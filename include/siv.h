@@ -296,6 +296,28 @@ int siv_bn_act_bwd(const float* dout, const float* y, const float* mean, const f
                    float* dy, float* dgamma, float* dbeta, float* dresidual, int accumulate,
                    int N, int D, int H, int W, int C,
                    void* ws, size_t ws_bytes, siv_stream_t stream);
+/* The same three operators for a batch that consists of `groups` equal parts which the reference sends through
+ * the layer in SEPARATE calls with the same weights -- model.forward(rec.detach()) then model.forward(fake.detach()),
+ * decode(noise) then decode(z), encode(rec) then encode(fake), decode(z_rec) then decode(z_fake)
+ * (utils/my_trainer.py:266-267, 297-298, 304-311) -- and which are run here as one batch so that the small deep
+ * layers fill the chip: part g (samples [g*N/groups, (g+1)*N/groups)) is normalised with its own batch statistics
+ * mean[g][C], var[g][C]; the running statistics receive one update per part, in part order, and
+ * num_batches_tracked += groups, exactly as after `groups` consecutive calls; dgamma / dbeta are the sums over the
+ * parts.  M of siv_bn_stats_grouped is the number of rows of ONE part; N of the other two is the whole batch
+ * (N % groups == 0).  groups == 1 is the plain operator. */
+int siv_bn_stats_grouped(const float* y, long M, int C, int groups, float* mean, float* var,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                         float momentum, void* ws, size_t ws_bytes, siv_stream_t stream);
+int siv_bn_act_fwd_grouped(const float* y, const float* mean, const float* var,
+                           const float* gamma, const float* beta, const float* residual,
+                           const uint8_t* keep, float p, float slope, int pool, float eps,
+                           float* out, int N, int D, int H, int W, int C, int groups, siv_stream_t stream);
+int siv_bn_act_bwd_grouped(const float* dout, const float* y, const float* mean, const float* var,
+                           const float* gamma, const float* beta, const float* residual,
+                           const uint8_t* keep, float p, float slope, int pool, float eps,
+                           float* dy, float* dgamma, float* dbeta, float* dresidual, int accumulate,
+                           int N, int D, int H, int W, int C, int groups,
+                           void* ws, size_t ws_bytes, siv_stream_t stream);
 /* out = dropout(act(x)) without normalisation: the decoder tail nn.ReLU + nn.Dropout(0.35)
  * of models/models.py:139-140, and its backward (dx = dout * keep/(1-p) * act'(x)). */
 int siv_act_dropout_fwd(const float* x, const uint8_t* keep, float p, float slope,

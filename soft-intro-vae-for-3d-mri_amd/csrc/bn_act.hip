@@ -36,6 +36,8 @@ __device__ __forceinline__ ChanMap chan_map(int C) {
 __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ y, long M, int C,
                                                         float* __restrict__ part) {
     extern __shared__ float sh[];  // [2][256]
+    y += (long)blockIdx.y * M * C;                       // group
+    part += (long)blockIdx.y * gridDim.x * 2 * C;
     const ChanMap m = chan_map(C);
     const long rows_per_block = (M + gridDim.x - 1) / gridDim.x;
     const long r0 = (long)blockIdx.x * rows_per_block;
@@ -68,6 +70,10 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
     }
 }
 
+// Groups: a batch may consist of `groups` equal parts that are normalised separately (each part is what the
+// reference passes through the layer in a call of its own).  Group g owns rows [g*M, (g+1)*M) of the tensor,
+// partial rows [g*prow, g*prow + nblk) and statistics [g][C]; the running statistics are updated once per group,
+// in group order, as by consecutive calls.
 // one wave per channel: lanes stride over the per-block partials, fixed-order wave reduction
 __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict__ y,
                                                          const float* __restrict__ part, int nblk,
@@ -75,29 +81,33 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(const float* __restrict
                                                          float* __restrict__ var,
                                                          float* __restrict__ rmean,
                                                          float* __restrict__ rvar,
-                                                         int64_t* __restrict__ nbt, float momentum) {
+                                                         int64_t* __restrict__ nbt, float momentum,
+                                                         int groups, long prow, long ystride) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += groups;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-        s1 += (double)part[((long)b * 2 + 0) * C + c];
-        s2 += (double)part[((long)b * 2 + 1) * C + c];
-    }
-    s1 = wave_sum_d(s1);
-    s2 = wave_sum_d(s2);
-    if (lane != 0) return;
-    const double ms = s1 / (double)M;
-    double v = s2 / (double)M - ms * ms;
-    if (v < 0.0) v = 0.0;
-    const double mu = (y ? (double)y[c] : 0.0) + ms;
-    mean[c] = (float)mu;
-    var[c] = (float)v;
-    if (rmean) {
-        const double unb = (M > 1) ? v * ((double)M / (double)(M - 1)) : v;
-        rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mu);
-        rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+    for (int g = 0; g < groups; ++g) {
+        const float* pg = part + (long)g * prow * 2 * C;
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = lane; b < nblk; b += 64) {
+            s1 += (double)pg[((long)b * 2 + 0) * C + c];
+            s2 += (double)pg[((long)b * 2 + 1) * C + c];
+        }
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+        if (lane != 0) continue;
+        const double ms = s1 / (double)M;
+        double v = s2 / (double)M - ms * ms;
+        if (v < 0.0) v = 0.0;
+        const double mu = (y ? (double)y[(long)g * ystride + c] : 0.0) + ms;     // y: the shift the partials were taken against
+        mean[g * C + c] = (float)mu;
+        var[g * C + c] = (float)v;
+        if (rmean) {
+            const double unb = (M > 1) ? v * ((double)M / (double)(M - 1)) : v;
+            rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mu);
+            rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+        }
     }
 }
 
@@ -273,25 +283,31 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
 }
 
 // sums[0][c] = sum dz, sums[1][c] = sum dz*xhat; also dgamma/dbeta.  One wave per channel.
+// Groups as above: sums[g][2][C]; dgamma / dbeta receive the groups' contributions one after the other.
 __global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__ part, int nblk, int C,
                                                        float* __restrict__ sums,
                                                        float* __restrict__ dgamma,
-                                                       float* __restrict__ dbeta, int accumulate) {
+                                                       float* __restrict__ dbeta, int accumulate,
+                                                       int groups, long prow) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-        s1 += (double)part[((long)b * 2 + 0) * C + c];
-        s2 += (double)part[((long)b * 2 + 1) * C + c];
+    for (int g = 0; g < groups; ++g) {
+        const float* pg = part + (long)g * prow * 2 * C;
+        double s1 = 0.0, s2 = 0.0;
+        for (int b = lane; b < nblk; b += 64) {
+            s1 += (double)pg[((long)b * 2 + 0) * C + c];
+            s2 += (double)pg[((long)b * 2 + 1) * C + c];
+        }
+        s1 = wave_sum_d(s1);
+        s2 = wave_sum_d(s2);
+        if (lane != 0) continue;
+        sums[(long)g * 2 * C + c] = (float)s1;
+        sums[(long)g * 2 * C + C + c] = (float)s2;
+        const bool acc = accumulate || g > 0;
+        if (dbeta) dbeta[c] = acc ? dbeta[c] + (float)s1 : (float)s1;
+        if (dgamma) dgamma[c] = acc ? dgamma[c] + (float)s2 : (float)s2;
     }
-    s1 = wave_sum_d(s1);
-    s2 = wave_sum_d(s2);
-    if (lane != 0) return;
-    sums[c] = (float)s1;
-    sums[C + c] = (float)s2;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
 }
 
 template <int POOL>
@@ -434,6 +450,8 @@ __device__ __forceinline__ void block_reduce_quads(float4 s1, float4 s2, int C4,
 __global__ __launch_bounds__(256) void bn_stats_partial_v(const float* __restrict__ y, long Q, int C,
                                                           float* __restrict__ part) {
     __shared__ float4 sh[512];
+    y += (long)blockIdx.y * Q * 4;                       // group: Q quads each
+    part += (long)blockIdx.y * gridDim.x * 2 * C;
     const int C4 = C >> 2;
     const float4 shift = ld4(y, threadIdx.x % C4);
     float4 s1 = f4(0.f), s2 = f4(0.f);
@@ -484,6 +502,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_v(const float* __restrict__ y,
                                                     const uint8_t* __restrict__ keep, float p,
                                                     float slope, float eps, float* __restrict__ out,
                                                     long OQ, PoolGeom g) {
+    {   // group blockIdx.y: OQ output quads (8 OQ input quads when pooled), its own statistics
+        const long go = (long)blockIdx.y * OQ * 4, gi = go * (POOL == 2 ? 8 : 1);
+        y += gi, out += go, mean += blockIdx.y * g.C4 * 4, var += blockIdx.y * g.C4 * 4;
+        if (res) res += gi;
+        if (keep) keep += go;
+    }
     const Coef k = load_coef(mean, var, gamma, beta, eps, threadIdx.x % g.C4);
     const float dscale = 1.0f / (1.0f - p);
     const long T = (long)gridDim.x * 256;
@@ -555,6 +579,18 @@ __global__ __launch_bounds__(256) void bn_bwd_v(const float* __restrict__ dout,
                                                 long OQ, PoolGeom g, int C, float* __restrict__ part,
                                                 float* __restrict__ dy, float* __restrict__ dres) {
     __shared__ float4 sh[APPLY ? 1 : 512];
+    {   // group blockIdx.y (see bn_act_fwd_v): its own statistics, sums and partial rows
+        const long go = (long)blockIdx.y * OQ * 4, gi = go * (POOL == 2 ? 8 : 1);
+        dout += go, y += gi, mean += blockIdx.y * C, var += blockIdx.y * C;
+        if (keep) keep += go;
+        if (res) res += gi;
+        if (APPLY) {
+            sums += (long)blockIdx.y * 2 * C, dy += gi;
+            if (dres) dres += gi;
+        } else {
+            part += (long)blockIdx.y * gridDim.x * 2 * C;
+        }
+    }
     const int c4 = threadIdx.x % g.C4;
     const Coef k = load_coef(mean, var, gamma, beta, eps, c4);
     float4 k1 = f4(0.f), k2 = f4(0.f);
@@ -678,6 +714,7 @@ static inline int stat_blocks(long M) {
 // 16 CUs).  Folded onto G = 256 rows first, whole rows per block, the two launches take ~10 us.
 constexpr int FOLD_ROWS = 256, FOLD_MIN_ROWS = 1024;
 __global__ __launch_bounds__(256) void rows_fold_k(float* __restrict__ part, int nrows, int cols) {
+    part += (long)blockIdx.y * nrows * cols;             // group: its own nrows rows
     const long G = gridDim.x;
     for (int col = threadIdx.x; col < cols; col += 256) {
         double a[8];
@@ -697,9 +734,9 @@ __global__ __launch_bounds__(256) void rows_fold_k(float* __restrict__ part, int
     }
 }
 // part is workspace of the caller's: folding overwrites its first FOLD_ROWS rows
-static int fold_rows(const float* part, int nblk, int cols, hipStream_t s) {
+static int fold_rows(const float* part, int nblk, int cols, hipStream_t s, int groups = 1) {
     if (nblk < FOLD_MIN_ROWS) return nblk;
-    rows_fold_k<<<FOLD_ROWS, 256, 0, s>>>(const_cast<float*>(part), nblk, cols);
+    rows_fold_k<<<dim3(FOLD_ROWS, groups), 256, 0, s>>>(const_cast<float*>(part), nblk, cols);
     return FOLD_ROWS;
 }
 
@@ -707,27 +744,34 @@ static int fold_rows(const float* part, int nblk, int cols, hipStream_t s) {
 
 using namespace siv;
 
-extern "C" int siv_bn_stats(const float* y, long M, int C, float* mean, float* var,
-                            float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                            float momentum, void* ws, size_t ws_bytes, siv_stream_t stream) {
+extern "C" int siv_bn_stats_grouped(const float* y, long M, int C, int groups, float* mean, float* var,
+                                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                    float momentum, void* ws, size_t ws_bytes, siv_stream_t stream) {
     SIV_CHECK_ARG(y && mean && var, "bn_stats: null pointer");
-    SIV_CHECK_ARG(M > 0 && C > 0, "bn_stats: bad shape M=%ld C=%d", M, C);
+    SIV_CHECK_ARG(M > 0 && C > 0 && groups > 0 && groups <= 65535, "bn_stats: bad shape M=%ld C=%d groups=%d", M, C, groups);
     SIV_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr),
                   "bn_stats: running_mean and running_var must both be given or both be NULL");
     const bool vec = vec_channels(C) && aligned16(y) && aligned16(ws);
     const int nblk = vec ? vec_grid(M * (C / 4), 8) : stat_blocks(M);
-    SIV_CHECK_WS((size_t)nblk * 2 * C * sizeof(float), ws_bytes, "bn_stats");
+    SIV_CHECK_WS((size_t)groups * nblk * 2 * C * sizeof(float), ws_bytes, "bn_stats");
     hipStream_t s = (hipStream_t)stream;
     if (vec)
-        bn_stats_partial_v<<<nblk, 256, 0, s>>>(y, M * (C / 4), C, (float*)ws);
+        bn_stats_partial_v<<<dim3(nblk, groups), 256, 0, s>>>(y, M * (C / 4), C, (float*)ws);
     else
-        bn_stats_partial<<<nblk, 256, 512 * sizeof(float), s>>>(y, M, C, (float*)ws);
+        bn_stats_partial<<<dim3(nblk, groups), 256, 512 * sizeof(float), s>>>(y, M, C, (float*)ws);
     SIV_CHECK_LAUNCH("bn_stats(partial)");
-    bn_stats_finalize<<<(C + 3) / 4, 256, 0, s>>>(y, (const float*)ws, fold_rows((const float*)ws, nblk, 2 * C, s), M, C, mean, var,
-                                                      running_mean, running_var,
-                                                      num_batches_tracked, momentum);
+    const int nfold = fold_rows((const float*)ws, nblk, 2 * C, s, groups);
+    bn_stats_finalize<<<(C + 3) / 4, 256, 0, s>>>(y, (const float*)ws, nfold, M, C, mean, var, running_mean,
+                                                      running_var, num_batches_tracked, momentum, groups, nblk,
+                                                      M * C);
     SIV_CHECK_LAUNCH("bn_stats(finalize)");
     return SIV_OK;
+}
+extern "C" int siv_bn_stats(const float* y, long M, int C, float* mean, float* var,
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                            float momentum, void* ws, size_t ws_bytes, siv_stream_t stream) {
+    return siv_bn_stats_grouped(y, M, C, 1, mean, var, running_mean, running_var, num_batches_tracked, momentum, ws,
+                                ws_bytes, stream);
 }
 
 namespace siv {
@@ -742,7 +786,7 @@ int bn_finalize_launch(const float* shift, const float* part, int nblk, long M, 
                                                   running_var, nbt, momentum);
     else
         bn_stats_finalize<<<(C + 3) / 4, 256, 0, s>>>(shift, part, nblk, M, C, mean, var, running_mean,
-                                                          running_var, nbt, momentum);
+                                                          running_var, nbt, momentum, 1, 0, 0);
     SIV_CHECK_LAUNCH("bn_stats(finalize)");
     return SIV_OK;
 }
@@ -750,69 +794,89 @@ int bn_finalize_launch(const float* shift, const float* part, int nblk, long M, 
 int bn_bwd_finalize_launch(const float* part, int nblk, int C, float* sums, float* dgamma, float* dbeta,
                            int accumulate, hipStream_t s) {
     nblk = fold_rows(part, nblk, 2 * C, s);
-    bn_bwd_finalize<<<(C + 3) / 4, 256, 0, s>>>(part, nblk, C, sums, dgamma, dbeta, accumulate);
+    bn_bwd_finalize<<<(C + 3) / 4, 256, 0, s>>>(part, nblk, C, sums, dgamma, dbeta, accumulate, 1, 0);
     SIV_CHECK_LAUNCH("bn_bwd(finalize)");
     return SIV_OK;
 }
 }  // namespace siv
 
-extern "C" int siv_bn_act_fwd(const float* y, const float* mean, const float* var,
-                              const float* gamma, const float* beta, const float* residual,
-                              const uint8_t* keep, float p, float slope, int pool, float eps,
-                              float* out, int N, int D, int H, int W, int C, siv_stream_t stream) {
+extern "C" int siv_bn_act_fwd_grouped(const float* y, const float* mean, const float* var,
+                                      const float* gamma, const float* beta, const float* residual,
+                                      const uint8_t* keep, float p, float slope, int pool, float eps,
+                                      float* out, int N, int D, int H, int W, int C, int groups,
+                                      siv_stream_t stream) {
     SIV_CHECK_ARG(y && mean && var && gamma && beta && out, "bn_act_fwd: null pointer");
     SIV_CHECK_ARG(N > 0 && D > 0 && H > 0 && W > 0 && C > 0, "bn_act_fwd: bad shape");
+    SIV_CHECK_ARG(groups > 0 && groups <= 65535 && N % groups == 0,
+                  "bn_act_fwd: the batch (%d) must be a multiple of the number of groups (%d)", N, groups);
     SIV_CHECK_ARG(pool == 1 || pool == 2, "bn_act_fwd: pool must be 1 or 2 (got %d)", pool);
     SIV_CHECK_ARG(pool == 1 || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0),
                   "bn_act_fwd: pool=2 needs even extents (got %d,%d,%d)", D, H, W);
     SIV_CHECK_ARG(p >= 0.f && p < 1.f, "bn_act_fwd: dropout p out of range");
     hipStream_t s = (hipStream_t)stream;
-    const long total = (long)N * (D / pool) * (H / pool) * (W / pool) * C;
-    if (vec_channels(C) && (long)N * D * H * W < (1L << 31) && aligned16(y) && aligned16(out) &&
+    const int Ng = N / groups;                                    // samples per group
+    const long total = (long)Ng * (D / pool) * (H / pool) * (W / pool) * C;      // output elements per group
+    if (vec_channels(C) && (long)Ng * D * H * W < (1L << 31) && aligned16(y) && aligned16(out) &&
         aligned16(residual) && aligned16(mean) && aligned16(var) && aligned16(gamma) && aligned16(beta) &&
         ((uintptr_t)keep & 3) == 0) {
         const PoolGeom g = {D / pool, H / pool, W / pool, H, W, C / 4, ilog2(C / 4)};
         const long OQ = total / 4;
         if (pool == 1)
-            bn_act_fwd_v<1><<<vec_grid_apply(OQ, 4), 256, 0, s>>>(y, mean, var, gamma, beta, residual, keep, p,
-                                                            slope, eps, out, OQ, g);
+            bn_act_fwd_v<1><<<dim3(vec_grid_apply(OQ, 4), groups), 256, 0, s>>>(y, mean, var, gamma, beta, residual,
+                                                                             keep, p, slope, eps, out, OQ, g);
         else
-            bn_act_fwd_v<2><<<vec_grid_apply(OQ, 1), 256, 0, s>>>(y, mean, var, gamma, beta, residual, keep, p,
-                                                            slope, eps, out, OQ, g);
+            bn_act_fwd_v<2><<<dim3(vec_grid_apply(OQ, 1), groups), 256, 0, s>>>(y, mean, var, gamma, beta, residual,
+                                                                             keep, p, slope, eps, out, OQ, g);
         SIV_CHECK_LAUNCH("bn_act_fwd");
         return SIV_OK;
     }
-    if (pool == 1)
-        bn_act_fwd_k<1><<<stream_grid(total), 256, 0, s>>>(y, mean, var, gamma, beta, residual, keep, p,
-                                                           slope, eps, out, N, D, H, W, C);
-    else
-        bn_act_fwd_k<2><<<stream_grid(total), 256, 0, s>>>(y, mean, var, gamma, beta, residual, keep, p,
-                                                           slope, eps, out, N, D, H, W, C);
-    SIV_CHECK_LAUNCH("bn_act_fwd");
+    const long in_total = (long)Ng * D * H * W * C;
+    for (int gi = 0; gi < groups; ++gi) {                         // scalar kernels: one launch per group
+        const float* yg = y + gi * in_total;
+        const float* rg = residual ? residual + gi * in_total : nullptr;
+        const uint8_t* kg = keep ? keep + gi * total : nullptr;
+        if (pool == 1)
+            bn_act_fwd_k<1><<<stream_grid(total), 256, 0, s>>>(yg, mean + gi * C, var + gi * C, gamma, beta, rg, kg, p,
+                                                               slope, eps, out + gi * total, Ng, D, H, W, C);
+        else
+            bn_act_fwd_k<2><<<stream_grid(total), 256, 0, s>>>(yg, mean + gi * C, var + gi * C, gamma, beta, rg, kg, p,
+                                                               slope, eps, out + gi * total, Ng, D, H, W, C);
+        SIV_CHECK_LAUNCH("bn_act_fwd");
+    }
     return SIV_OK;
 }
-
-extern "C" int siv_bn_act_bwd(const float* dout, const float* y, const float* mean, const float* var,
+extern "C" int siv_bn_act_fwd(const float* y, const float* mean, const float* var,
                               const float* gamma, const float* beta, const float* residual,
                               const uint8_t* keep, float p, float slope, int pool, float eps,
-                              float* dy, float* dgamma, float* dbeta, float* dresidual,
-                              int accumulate, int N, int D, int H, int W, int C, void* ws,
-                              size_t ws_bytes, siv_stream_t stream) {
+                              float* out, int N, int D, int H, int W, int C, siv_stream_t stream) {
+    return siv_bn_act_fwd_grouped(y, mean, var, gamma, beta, residual, keep, p, slope, pool, eps, out, N, D, H, W, C,
+                                  1, stream);
+}
+
+extern "C" int siv_bn_act_bwd_grouped(const float* dout, const float* y, const float* mean, const float* var,
+                                      const float* gamma, const float* beta, const float* residual,
+                                      const uint8_t* keep, float p, float slope, int pool, float eps,
+                                      float* dy, float* dgamma, float* dbeta, float* dresidual,
+                                      int accumulate, int N, int D, int H, int W, int C, int groups, void* ws,
+                                      size_t ws_bytes, siv_stream_t stream) {
     SIV_CHECK_ARG(dout && y && mean && var && gamma && beta && dy, "bn_act_bwd: null pointer");
     SIV_CHECK_ARG(N > 0 && D > 0 && H > 0 && W > 0 && C > 0, "bn_act_bwd: bad shape");
+    SIV_CHECK_ARG(groups > 0 && groups <= 65535 && N % groups == 0,
+                  "bn_act_bwd: the batch (%d) must be a multiple of the number of groups (%d)", N, groups);
     SIV_CHECK_ARG(pool == 1 || pool == 2, "bn_act_bwd: pool must be 1 or 2 (got %d)", pool);
     SIV_CHECK_ARG(pool == 1 || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0),
                   "bn_act_bwd: pool=2 needs even extents");
     SIV_CHECK_ARG(dresidual == nullptr || residual != nullptr,
                   "bn_act_bwd: dresidual requested without residual");
-    const long M = (long)N * D * H * W;
+    const int Ng = N / groups;
+    const long M = (long)Ng * D * H * W;                          // rows per group
     const bool vec = vec_channels(C) && M < (1L << 31) && aligned16(dout) && aligned16(y) && aligned16(dy) &&
                      aligned16(residual) && aligned16(dresidual) && aligned16(mean) && aligned16(var) &&
                      aligned16(gamma) && aligned16(beta) && aligned16(ws) && ((uintptr_t)keep & 3) == 0;
-    const long OQ = (long)N * (D / pool) * (H / pool) * (W / pool) * (C / 4);   // loop extent of the float4 path
+    const long OQ = (long)Ng * (D / pool) * (H / pool) * (W / pool) * (C / 4);   // loop extent of the float4 path
     const int nblk = vec ? vec_grid(OQ, pool == 1 ? 8 : 2) : stat_blocks(M);
-    const size_t part_bytes = align256((size_t)nblk * 2 * C * sizeof(float));
-    SIV_CHECK_WS(part_bytes + (size_t)2 * C * sizeof(float), ws_bytes, "bn_act_bwd");
+    const size_t part_bytes = align256((size_t)groups * nblk * 2 * C * sizeof(float));
+    SIV_CHECK_WS(part_bytes + (size_t)groups * 2 * C * sizeof(float), ws_bytes, "bn_act_bwd");
     float* part = (float*)ws;
     float* sums = (float*)((char*)ws + part_bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -820,46 +884,62 @@ extern "C" int siv_bn_act_bwd(const float* dout, const float* y, const float* me
         const PoolGeom g = {D / pool, H / pool, W / pool, H, W, C / 4, ilog2(C / 4)};
         const float invM = 1.0f / (float)M;
         if (pool == 1)
-            bn_bwd_v<1, 0><<<nblk, 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual, keep, p, slope, eps,
-                                                nullptr, invM, OQ, g, C, part, nullptr, nullptr);
+            bn_bwd_v<1, 0><<<dim3(nblk, groups), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual, keep, p, slope,
+                                                              eps, nullptr, invM, OQ, g, C, part, nullptr, nullptr);
         else
-            bn_bwd_v<2, 0><<<nblk, 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual, keep, p, slope, eps,
-                                                nullptr, invM, OQ, g, C, part, nullptr, nullptr);
+            bn_bwd_v<2, 0><<<dim3(nblk, groups), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual, keep, p, slope,
+                                                              eps, nullptr, invM, OQ, g, C, part, nullptr, nullptr);
         SIV_CHECK_LAUNCH("bn_act_bwd(partial)");
-        bn_bwd_finalize<<<(C + 3) / 4, 256, 0, s>>>(part, fold_rows(part, nblk, 2 * C, s), C, sums, dgamma, dbeta, accumulate);
+        const int nfold = fold_rows(part, nblk, 2 * C, s, groups);
+        bn_bwd_finalize<<<(C + 3) / 4, 256, 0, s>>>(part, nfold, C, sums, dgamma, dbeta, accumulate, groups, nblk);
         SIV_CHECK_LAUNCH("bn_act_bwd(finalize)");
         if (pool == 1)
-            bn_bwd_v<1, 1><<<vec_grid_apply(OQ, 4), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual, keep, p,
-                                                           slope, eps, sums, invM, OQ, g, C, nullptr, dy,
-                                                           dresidual);
+            bn_bwd_v<1, 1><<<dim3(vec_grid_apply(OQ, 4), groups), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual,
+                                                                            keep, p, slope, eps, sums, invM, OQ, g, C,
+                                                                            nullptr, dy, dresidual);
         else
-            bn_bwd_v<2, 1><<<vec_grid_apply(OQ, 1), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual, keep, p,
-                                                           slope, eps, sums, invM, OQ, g, C, nullptr, dy,
-                                                           dresidual);
+            bn_bwd_v<2, 1><<<dim3(vec_grid_apply(OQ, 1), groups), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual,
+                                                                            keep, p, slope, eps, sums, invM, OQ, g, C,
+                                                                            nullptr, dy, dresidual);
         SIV_CHECK_LAUNCH("bn_act_bwd(apply)");
         return SIV_OK;
     }
-    if (pool == 1)
-        bn_bwd_partial<1><<<nblk, 256, 512 * sizeof(float), s>>>(dout, y, mean, var, gamma, beta,
-                                                                 residual, keep, p, slope, eps, M, D,
-                                                                 H, W, C, part);
-    else
-        bn_bwd_partial<2><<<nblk, 256, 512 * sizeof(float), s>>>(dout, y, mean, var, gamma, beta,
-                                                                 residual, keep, p, slope, eps, M, D,
-                                                                 H, W, C, part);
-    SIV_CHECK_LAUNCH("bn_act_bwd(partial)");
-    bn_bwd_finalize<<<(C + 3) / 4, 256, 0, s>>>(part, fold_rows(part, nblk, 2 * C, s), C, sums, dgamma, dbeta, accumulate);
-    SIV_CHECK_LAUNCH("bn_act_bwd(finalize)");
-    if (pool == 1)
-        bn_bwd_apply<1><<<stream_grid(M * C), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual,
-                                                           keep, p, slope, eps, sums, M, D, H, W, C,
-                                                           dy, dresidual);
-    else
-        bn_bwd_apply<2><<<stream_grid(M * C), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual,
-                                                           keep, p, slope, eps, sums, M, D, H, W, C,
-                                                           dy, dresidual);
-    SIV_CHECK_LAUNCH("bn_act_bwd(apply)");
+    const long in_total = M * C, out_total = (long)Ng * (D / pool) * (H / pool) * (W / pool) * C;
+    for (int gi = 0; gi < groups; ++gi) {                         // scalar kernels: one launch sequence per group
+        const float* dg = dout + gi * out_total;
+        const float* yg = y + gi * in_total;
+        const float* rg = residual ? residual + gi * in_total : nullptr;
+        const uint8_t* kg = keep ? keep + gi * out_total : nullptr;
+        float* drg = dresidual ? dresidual + gi * in_total : nullptr;
+        const float *mg = mean + gi * C, *vg = var + gi * C;
+        if (pool == 1)
+            bn_bwd_partial<1><<<nblk, 256, 512 * sizeof(float), s>>>(dg, yg, mg, vg, gamma, beta, rg, kg, p, slope, eps,
+                                                                     M, D, H, W, C, part);
+        else
+            bn_bwd_partial<2><<<nblk, 256, 512 * sizeof(float), s>>>(dg, yg, mg, vg, gamma, beta, rg, kg, p, slope, eps,
+                                                                     M, D, H, W, C, part);
+        SIV_CHECK_LAUNCH("bn_act_bwd(partial)");
+        bn_bwd_finalize<<<(C + 3) / 4, 256, 0, s>>>(part, fold_rows(part, nblk, 2 * C, s), C, sums, dgamma, dbeta,
+                                                    accumulate || gi > 0, 1, 0);
+        SIV_CHECK_LAUNCH("bn_act_bwd(finalize)");
+        if (pool == 1)
+            bn_bwd_apply<1><<<stream_grid(M * C), 256, 0, s>>>(dg, yg, mg, vg, gamma, beta, rg, kg, p, slope, eps, sums,
+                                                               M, D, H, W, C, dy + gi * in_total, drg);
+        else
+            bn_bwd_apply<2><<<stream_grid(M * C), 256, 0, s>>>(dg, yg, mg, vg, gamma, beta, rg, kg, p, slope, eps, sums,
+                                                               M, D, H, W, C, dy + gi * in_total, drg);
+        SIV_CHECK_LAUNCH("bn_act_bwd(apply)");
+    }
     return SIV_OK;
+}
+extern "C" int siv_bn_act_bwd(const float* dout, const float* y, const float* mean, const float* var,
+                              const float* gamma, const float* beta, const float* residual,
+                              const uint8_t* keep, float p, float slope, int pool, float eps,
+                              float* dy, float* dgamma, float* dbeta, float* dresidual,
+                              int accumulate, int N, int D, int H, int W, int C, void* ws,
+                              size_t ws_bytes, siv_stream_t stream) {
+    return siv_bn_act_bwd_grouped(dout, y, mean, var, gamma, beta, residual, keep, p, slope, pool, eps, dy, dgamma,
+                                  dbeta, dresidual, accumulate, N, D, H, W, C, 1, ws, ws_bytes, stream);
 }
 
 extern "C" int siv_act_dropout_fwd(const float* x, const uint8_t* keep, float p, float slope,

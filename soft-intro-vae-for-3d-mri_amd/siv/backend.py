@@ -117,6 +117,10 @@ class HipBackend:
                 with torch.cuda.device(flat.device):
                     self.lib.siv_pack_cache_invalidate_range(flat.data_ptr(), flat.numel() * flat.element_size())
             return
+        if device is not None:
+            device = torch.device(device)
+            if device.type == "cuda" and device.index is None:      # "cuda" = the current device
+                device = torch.device("cuda", torch.cuda.current_device())
         for dev in ([device] if device is not None else list(self._pack_cache)):
             if dev in self._pack_cache:
                 with torch.cuda.device(dev):
@@ -508,20 +512,33 @@ class HipBackend:
         return out
 
     # ---- batch norm + activation tail --------------------------------------------
-    def bn_stats(self, y, running_mean, running_var, nbt, momentum: float):
+    def bn_stats(self, y, running_mean, running_var, nbt, momentum: float, groups: int = 1):
+        """Batch statistics (mean, biased variance) of ``y``; with ``groups`` > 1 one pair per consecutive part of
+        the batch, shape (groups, C), and one running-statistics update per part, in part order."""
         self._check_dev(y, running_mean, running_var, nbt)
         y = cl(y)
         N, C, D, H, W = y.shape
-        mean = torch.empty(C, device=y.device, dtype=torch.float32)
-        var = torch.empty(C, device=y.device, dtype=torch.float32)
+        if N % groups:
+            raise _lib.SivError(f"bn_stats: batch {N} is not a multiple of {groups} groups")
+        shape = (C,) if groups == 1 else (groups, C)
+        mean = torch.empty(shape, device=y.device, dtype=torch.float32)
+        var = torch.empty(shape, device=y.device, dtype=torch.float32)
         ws, wsb = self._workspace(y)
-        _lib.check(self.lib.siv_bn_stats(_p(y), N * D * H * W, C, _p(mean), _p(var), _p(running_mean),
-                                         _p(running_var), _p(nbt), float(momentum), ws, wsb,
-                                         self._stream(y)), "siv_bn_stats")
+        _lib.check(self.lib.siv_bn_stats_grouped(_p(y), (N // groups) * D * H * W, C, groups, _p(mean), _p(var),
+                                                 _p(running_mean), _p(running_var), _p(nbt), float(momentum), ws,
+                                                 wsb, self._stream(y)), "siv_bn_stats")
         return mean, var
 
+    @staticmethod
+    def _groups_of(mean) -> int:
+        return 1 if mean.dim() == 1 else int(mean.shape[0])
+
     def bn_act_fwd(self, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps):
+        """``mean`` / ``var`` of shape (groups, C) select the grouped operator (one set of statistics per
+        consecutive part of the batch)."""
         self._check_dev(y, mean, var, gamma, beta, res, keep)
+        groups = self._groups_of(mean)
+        mean, var = mean.contiguous(), var.contiguous()
         y = cl(y)
         res = cl(res) if res is not None else None
         N, C, D, H, W = y.shape
@@ -529,15 +546,17 @@ class HipBackend:
         if keep is not None:
             keep = cl(keep)
             assert keep.dtype == torch.uint8 and keep.shape == out.shape
-        _lib.check(self.lib.siv_bn_act_fwd(_p(y), _p(mean), _p(var), _p(gamma), _p(beta), _p(res), _p(keep),
-                                           float(p), float(slope), int(pool), float(eps), _p(out),
-                                           N, D, H, W, C, self._stream(y)), "siv_bn_act_fwd")
+        _lib.check(self.lib.siv_bn_act_fwd_grouped(_p(y), _p(mean), _p(var), _p(gamma), _p(beta), _p(res), _p(keep),
+                                                   float(p), float(slope), int(pool), float(eps), _p(out),
+                                                   N, D, H, W, C, groups, self._stream(y)), "siv_bn_act_fwd")
         return out
 
     def bn_act_bwd(self, dout, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps,
                    want_affine: bool, want_res: bool, dgamma_out=None, dbeta_out=None):
         """With ``dgamma_out`` / ``dbeta_out`` the affine gradients are ADDED into those buffers."""
         self._check_dev(dout, y, mean, var, gamma, beta, res, keep, dgamma_out, dbeta_out)
+        groups = self._groups_of(mean)
+        mean, var = mean.contiguous(), var.contiguous()
         dout, y = cl(dout), cl(y)
         res = cl(res) if res is not None else None
         keep = cl(keep) if keep is not None else None
@@ -552,10 +571,10 @@ class HipBackend:
             dbeta = torch.empty(C, device=y.device, dtype=torch.float32) if want_affine else None
         dres = like(y) if (want_res and res is not None) else None
         ws, wsb = self._workspace(y)
-        _lib.check(self.lib.siv_bn_act_bwd(_p(dout), _p(y), _p(mean), _p(var), _p(gamma), _p(beta), _p(res),
-                                           _p(keep), float(p), float(slope), int(pool), float(eps),
-                                           _p(dy), _p(dgamma), _p(dbeta), _p(dres), acc, N, D, H, W, C,
-                                           ws, wsb, self._stream(y)), "siv_bn_act_bwd")
+        _lib.check(self.lib.siv_bn_act_bwd_grouped(_p(dout), _p(y), _p(mean), _p(var), _p(gamma), _p(beta), _p(res),
+                                                   _p(keep), float(p), float(slope), int(pool), float(eps),
+                                                   _p(dy), _p(dgamma), _p(dbeta), _p(dres), acc, N, D, H, W, C,
+                                                   groups, ws, wsb, self._stream(y)), "siv_bn_act_bwd")
         return dy, dgamma, dbeta, dres
 
     def act_dropout_fwd(self, x, keep, p, slope):

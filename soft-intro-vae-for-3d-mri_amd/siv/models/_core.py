@@ -33,6 +33,13 @@ class Variant:
 SINTRO = Variant(0.2, 0.35, 0.25, 0.35)   # models/models.py:15,19,94-95,121-122,139-140
 PLAIN = Variant(0.0, 0.0, 0.0, 0.0)       # models/vaemodel.py:14,18,90,113,129
 
+# Paired passes.  The Soft-IntroVAE iteration sends two different batches through the same weights four times
+# (utils/my_trainer.py:266-267, 297-298, 304-311).  A pair runs the layers whose volumes are at most this many
+# voxels per sample (20x24x20 and below: launches that do not fill the chip at batch 8) as ONE batch with
+# BatchNorm statistics per member; the larger layers, the fused single-channel stem and the output layer run per
+# member as before.
+PAIR_MAX_VOXELS = 20 * 24 * 20
+
 
 def _act_module(v: Variant) -> nn.Module:
     return nn.LeakyReLU(v.slope, inplace=True) if v.slope != 0.0 else nn.ReLU(inplace=True)
@@ -85,11 +92,13 @@ class BuildingBlock(_ResBlockBase):
             nn.BatchNorm3d(out_ch),
         )
 
-    def forward(self, x):
+    def forward(self, x, groups: int = 1):
+        """``groups`` > 1: ``x`` is that many passes of the reference concatenated on the batch axis
+        (BatchNorm statistics per part)."""
         c1, b1, _, _, c2, b2 = self.block
         s = self.variant.slope
-        h = ops.conv_bn_act(x, c1, b1, s, pool=self.stride, train=self.training)
-        return ops.conv_bn_act(h, c2, b2, s, residual=self._res(x), train=self.training)
+        h = ops.conv_bn_act(x, c1, b1, s, pool=self.stride, train=self.training, groups=groups)
+        return ops.conv_bn_act(h, c2, b2, s, residual=self._res(x), train=self.training, groups=groups)
 
 
 class UpsampleBuildingkBlock(_ResBlockBase):
@@ -114,13 +123,14 @@ class UpsampleBuildingkBlock(_ResBlockBase):
             nn.BatchNorm3d(out_ch),
         )
 
-    def forward(self, x):
+    def forward(self, x, groups: int = 1):
         c1, b1, _, _, c2, b2 = self.block
         s = self.variant.slope
         if self.stride not in (1, 2):
             raise ValueError(f"only stride 1 or 2 is supported (got {self.stride})")
-        h = ops.conv_bn_act(x, c1, b1, s, train=self.training)
-        return ops.conv_bn_act(h, c2, b2, s, ups=self.stride, residual=self._res(x), train=self.training)
+        h = ops.conv_bn_act(x, c1, b1, s, train=self.training, groups=groups)
+        return ops.conv_bn_act(h, c2, b2, s, ups=self.stride, residual=self._res(x), train=self.training,
+                               groups=groups)
 
     def forward_unnormalised(self, x):
         """The block up to and including its second convolution: (raw output, batch statistics or None).
@@ -154,18 +164,50 @@ class ResNetEncoder(nn.Module):
         self.blocks = nn.Sequential(*blocks)
         self.conv = nn.Sequential(nn.Conv3d(in_ch, 1, kernel_size=1, stride=1, bias=True))
 
-    def features(self, x):
+    def _stem(self, x):
         v = self.variant
         conv, bn = self.blocks[0][0], self.blocks[0][1]
         fused = ops.conv1_bn_act_supported(x, conv)  # the stem's convolution output and mask are never stored
         keep = _keep((x.shape[0], conv.out_channels) + tuple(x.shape[2:]), v.p_enc_stem, self.training, x.device,
                      stored=not fused)
         if fused:
-            h = ops.conv1_bn_act(x, conv, bn, v.slope, keep=keep, p=v.p_enc_stem, train=self.training)
-        else:
-            h = ops.conv_bn_act(x, conv, bn, v.slope, keep=keep, p=v.p_enc_stem, train=self.training)
+            return ops.conv1_bn_act(x, conv, bn, v.slope, keep=keep, p=v.p_enc_stem, train=self.training)
+        return ops.conv_bn_act(x, conv, bn, v.slope, keep=keep, p=v.p_enc_stem, train=self.training)
+
+    def features(self, x):
+        h = self._stem(x)
         for blk in list(self.blocks)[1:]:
             h = blk[0](h)
+        return h
+
+    def n_draws(self) -> int:
+        """Random draws of one pass (the stem's dropout mask)."""
+        return int(self.training and self.variant.p_enc_stem > 0)
+
+    def features_pair(self, xs, cur: "rng.PairedDraws"):
+        """``features`` of every member of ``xs`` (same shapes), returned concatenated on the batch axis: the
+        stem and the blocks on large volumes run per member, the blocks from ``PAIR_MAX_VOXELS`` voxels per
+        sample down run once on the merged batch with BatchNorm statistics per member."""
+        blocks = [b[0] for b in list(self.blocks)[1:]]
+        vox = 1
+        for d in xs[0].shape[2:]:
+            vox *= int(d)
+        first_merged = len(blocks)
+        for i, blk in enumerate(blocks):
+            if vox <= PAIR_MAX_VOXELS:
+                first_merged = i
+                break
+            vox //= blk.stride ** 3
+        hs = []
+        for g, x in enumerate(xs):
+            with cur.member(g):
+                h = self._stem(x)
+                for blk in blocks[:first_merged]:
+                    h = blk(h)
+            hs.append(h)
+        h = torch.cat(hs)
+        for blk in blocks[first_merged:]:
+            h = blk(h, groups=len(xs))
         return h
 
     @activations.scoped
@@ -185,6 +227,12 @@ class VAEResNetEncoder(ResNetEncoder):
     @activations.scoped
     def forward(self, x):
         h = self.features(x)
+        return ops.conv1x1(h, self.mu.weight, self.mu.bias), ops.conv1x1(h, self.var.weight, self.var.bias)
+
+    @activations.scoped
+    def forward_pair(self, xs, cur):
+        """(mu, logvar) of all members of ``xs`` concatenated on the batch axis (see ``features_pair``)."""
+        h = self.features_pair(xs, cur)
         return ops.conv1x1(h, self.mu.weight, self.mu.bias), ops.conv1x1(h, self.var.weight, self.var.bias)
 
 
@@ -228,6 +276,55 @@ class ResNetDecoder(nn.Module):
         h = ops.bn_act(h, bn, v.slope, keep=keep, p=v.p_dec_stem, train=self.training)
         for blk in mods[1:-2]:
             h = blk[0](h)
+        return self._last_block_and_output(h, mods)
+
+    def n_draws(self) -> int:
+        """Random draws of one pass (stem and output dropout masks)."""
+        v = self.variant
+        return int(self.training and v.p_dec_stem > 0) + int(self.training and v.p_dec_out > 0)
+
+    @activations.scoped
+    def forward_pair(self, z, members: int, cur: "rng.PairedDraws"):
+        """``forward`` of ``members`` latents concatenated in ``z``: the 1x1x1 stem and the blocks whose output
+        has at most ``PAIR_MAX_VOXELS`` voxels per sample run once on the merged batch (BatchNorm statistics
+        and dropout masks per member), the rest, the last block and the output layer per member.  Returns the
+        list of the members' outputs."""
+        v = self.variant
+        mods = list(self.blocks)
+        conv, bn = mods[0][0], mods[0][1]
+        if z.shape[0] % members:
+            raise ValueError("the merged latent batch is not a multiple of the number of members")
+        per = z.shape[0] // members
+        h = ops.conv1x1(z, conv.weight, conv.bias)
+        keeps = []
+        for g in range(members):
+            with cur.member(g):
+                keeps.append(_keep((per,) + tuple(h.shape[1:]), v.p_dec_stem, self.training, h.device))
+        keep = torch.cat(keeps) if keeps[0] is not None else None
+        h = ops.bn_act(h, bn, v.slope, keep=keep, p=v.p_dec_stem, train=self.training, groups=members)
+        body = [m[0] for m in mods[1:-2]]
+        vox = 1
+        for d in z.shape[2:]:
+            vox *= int(d)
+        n_merged = 0
+        for blk in body:
+            vox *= blk.stride ** 3
+            if vox > PAIR_MAX_VOXELS:
+                break
+            n_merged += 1
+        for blk in body[:n_merged]:
+            h = blk(h, groups=members)
+        outs = []
+        for g in range(members):
+            hg = h[g * per:(g + 1) * per]
+            for blk in body[n_merged:]:
+                hg = blk(hg)
+            with cur.member(g):
+                outs.append(self._last_block_and_output(hg, mods))
+        return outs
+
+    def _last_block_and_output(self, h, mods):
+        v = self.variant
         last, conv = mods[-2][0], mods[-1][0]
         y = stats = None
         if len(mods) > 2 and isinstance(last, UpsampleBuildingkBlock) and not last.res and conv.out_channels == 1:
@@ -304,6 +401,52 @@ class SoftIntroVAE(nn.Module):
 
     def decode(self, z, y_cond=None):
         return self.decoder(z)
+
+    # ---- two passes through the same weights as one batch ------------------------------------------------
+    # The training iteration calls the network on two different batches in a row four times
+    # (utils/my_trainer.py:266-267, 297-298, 304-311).  The *_pair methods compute exactly what the two calls
+    # compute -- BatchNorm batch statistics and running-statistics updates per call, dropout masks and eps drawn
+    # with the call indices the two calls would use -- but run the small deep layers once on the merged batch.
+    # They return the merged (2B) latent tensors; member k owns rows [k*B, (k+1)*B).
+
+    def pair_ready(self) -> bool:
+        """Paired passes need a random source that addresses draws by call index, and training mode."""
+        return self.training and rng.seekable()
+
+    def decode_pair(self, za, zb=None):
+        """[decode(za), decode(zb)]; with ``zb`` None, ``za`` is the two latents already concatenated."""
+        z = za if zb is None else torch.cat([za, zb])
+        cur = rng.PairedDraws(self.decoder.n_draws())
+        outs = self.decoder.forward_pair(z, 2, cur)
+        cur.close()
+        return outs
+
+    def encode_reparam_pair(self, xa, xb):
+        """``mu, logvar = encode(x); z = reparameterize(mu, logvar)`` for ``xa`` then ``xb`` (:304-308):
+        returns merged (mu, logvar, z)."""
+        cur = rng.PairedDraws(self.encoder.n_draws() + 1)
+        mu, logvar = self.encoder.forward_pair([xa, xb], cur)
+        z = self._reparam_pair(mu, logvar, cur)
+        cur.close()
+        return mu, logvar, z
+
+    def forward_pair(self, xa, xb):
+        """``forward(xa)`` then ``forward(xb)`` (:266-267): returns merged (mu, logvar, z) and the list of
+        the two reconstructions."""
+        cur = rng.PairedDraws(self.encoder.n_draws() + 1 + self.decoder.n_draws())
+        mu, logvar = self.encoder.forward_pair([xa, xb], cur)
+        z = self._reparam_pair(mu, logvar, cur)
+        outs = self.decoder.forward_pair(z, 2, cur)
+        cur.close()
+        return mu, logvar, z, outs
+
+    def _reparam_pair(self, mu, logvar, cur):
+        per = mu.shape[0] // 2
+        eps = []
+        for g in range(2):
+            with cur.member(g):
+                eps.append(rng.get_rng().eps((per,) + tuple(mu.shape[1:]), mu.device))
+        return ops.reparameterize(mu, logvar, torch.cat(eps))
 
     def latent_shape(self, batch: int, dims):
         """Shape of the conv latent for input extents ``dims`` (the reference hard-codes

@@ -233,10 +233,15 @@ def add_act(a, b, slope: float):
 
 class _BnAct(Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, res, keep, bn, p, slope, pool, train, stats=None):
+    def forward(ctx, y, gamma, beta, res, keep, bn, p, slope, pool, train, stats=None, groups=1):
         B = get_backend()
         if train and stats is not None:
             mean, var = stats          # already computed (and the running statistics updated)
+        elif train and groups > 1:
+            # the batch is `groups` passes of the reference run as one: statistics (groups, C), one running
+            # update per part in part order; the kernels read the grouping off the shape of mean / var
+            mean, var = B.bn_stats(y, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                   BN_MOMENTUM if bn.momentum is None else bn.momentum, groups)
         elif train:
             mean, var = B.bn_stats(y, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                    BN_MOMENTUM if bn.momentum is None else bn.momentum)
@@ -267,23 +272,30 @@ class _BnAct(Function):
         if not ctx.needs_input_grad[0]:
             dy = None
         return (dy, dg if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None,
-                dres, None, None, None, None, None, None, None)
+                dres, None, None, None, None, None, None, None, None)
 
 
 def bn_act(y, bn, slope: float, pool: int = 1, residual=None, keep=None, p: float = 0.0,
-           train: bool = True, stats=None):
+           train: bool = True, stats=None, groups: int = 1):
     """BatchNorm3d (parameters/buffers of module ``bn``) -> [+residual] -> LeakyReLU(slope)
     -> AvgPool3d(pool) -> dropout(keep, p) as one fused pass.  ``stats`` = (mean, biased var) when
-    the producer of ``y`` already computed the batch statistics."""
+    the producer of ``y`` already computed the batch statistics.  ``groups`` > 1 (training mode): the batch is
+    that many passes of the reference concatenated; each part is normalised with its own batch statistics and
+    updates the running statistics once, in order."""
     if pool not in (1, 2):
         raise ValueError(f"only stride/pool 1 or 2 is supported (got {pool})")
-    return _BnAct.apply(y, bn.weight, bn.bias, residual, keep, bn, p, slope, pool, train, stats)
+    return _BnAct.apply(y, bn.weight, bn.bias, residual, keep, bn, p, slope, pool, train, stats,
+                        groups if train else 1)
 
 
 def conv_bn_act(x, conv, bn, slope: float, ups: int = 1, pool: int = 1, residual=None, keep=None,
-                p: float = 0.0, train: bool = True):
+                p: float = 0.0, train: bool = True, groups: int = 1):
     """conv3d_k3 (parameters of module ``conv``) followed by ``bn_act``.  In training mode the
-    convolution call also produces the BatchNorm batch statistics."""
+    convolution call also produces the BatchNorm batch statistics (one set); with ``groups`` > 1 the
+    statistics are per part of the batch and come from a pass of their own."""
+    if train and groups > 1:
+        y = _Conv3dK3.apply(x, conv.weight, conv.bias, ups, None)
+        return bn_act(y, bn, slope, pool, residual, keep, p, True, None, groups)
     if train:
         y, mean, var = _Conv3dK3.apply(x, conv.weight, conv.bias, ups, bn)
         return bn_act(y, bn, slope, pool, residual, keep, p, True, (mean, var))

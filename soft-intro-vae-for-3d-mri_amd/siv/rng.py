@@ -53,6 +53,14 @@ class DeviceRng:
         self.calls += 1
         return sid
 
+    def tell(self) -> int:
+        """Index of the next draw."""
+        return self.calls
+
+    def seek(self, index: int) -> None:
+        """The next draw gets call index ``index`` (draws are keyed by their index, not by a running state)."""
+        self.calls = int(index)
+
     def use_device_epoch(self, device) -> torch.Tensor:
         """From now on every draw adds ``epoch * 2^20`` to its stream id, ``epoch`` being a counter in
         device memory read when the kernel runs: draws captured in a HIP graph then differ from replay to
@@ -84,6 +92,15 @@ class ReplayRng:
     def __init__(self, source):
         self.source = source
 
+    def tell(self):
+        """Index of the next draw, or None when the source is a plain sequential generator."""
+        return getattr(self.source, "i", None)
+
+    def seek(self, index: int) -> None:
+        if not hasattr(self.source, "i"):
+            raise TypeError("this draw source cannot be repositioned")
+        self.source.i = int(index)
+
     def keep_mask(self, shape, p: float, device) -> torch.Tensor:
         m = self.source.mask(tuple(shape), p)
         return m.to(torch.uint8).to(device).contiguous(memory_format=torch.channels_last_3d)
@@ -92,6 +109,43 @@ class ReplayRng:
 
     def eps(self, shape, device) -> torch.Tensor:
         return self.source.eps(tuple(shape)).to(device)
+
+
+class PairedDraws:
+    """Draw indices for two (or more) network passes that the reference runs one after the other and that are
+    executed here interleaved, as one batch: member ``g`` makes ``stride`` draws in the reference, so its draws
+    own the call indices ``base + g * stride ...``.  ``with paired.member(g):`` positions the generator at member
+    g's next index and remembers where it stopped; ``close()`` checks that every member made exactly ``stride``
+    draws and leaves the generator behind the last member, where the reference would be."""
+
+    def __init__(self, stride: int, members: int = 2):
+        self.rng = get_rng()
+        base = self.rng.tell() if hasattr(self.rng, "tell") else None
+        if base is None:
+            raise TypeError("paired passes need a random source whose draws are addressed by call index")
+        self.base, self.stride, self.members = base, int(stride), int(members)
+        self.pos = [base + g * self.stride for g in range(self.members)]
+
+    @contextlib.contextmanager
+    def member(self, g: int):
+        self.rng.seek(self.pos[g])
+        try:
+            yield
+        finally:
+            self.pos[g] = self.rng.tell()
+
+    def close(self) -> None:
+        for g, p in enumerate(self.pos):
+            if p != self.base + (g + 1) * self.stride:
+                raise RuntimeError(f"pass {g} of a paired call made {p - self.base - g * self.stride} random draws, "
+                                   f"{self.stride} expected")
+        self.rng.seek(self.base + self.members * self.stride)
+
+
+def seekable() -> bool:
+    """True when the current generator addresses its draws by call index (``PairedDraws`` works)."""
+    r = get_rng()
+    return hasattr(r, "tell") and r.tell() is not None
 
 
 _current = DeviceRng(0)

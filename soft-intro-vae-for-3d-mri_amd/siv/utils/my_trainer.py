@@ -110,6 +110,8 @@ class SoftIntroStep:
         self.scale = scale
         self.sync = sync if sync is not None else GradSync(None)
         self._dec_draws = None        # random draws one decoder pass makes (known after the first one)
+        # SIV_PAIR=0: every pass in a launch sequence of its own, as the reference runs them
+        self.pair = os.environ.get("SIV_PAIR", "1") != "0"
 
     def flush(self) -> None:
         """Join a decoder update that a data-parallel job still has in flight (call before anything but the
@@ -155,13 +157,23 @@ class SoftIntroStep:
         fake, real_mu, real_logvar = self._first_two_passes(model, real_batch, noise_batch)
         z = model.reparameterize(real_mu, real_logvar)
         rec = model.decode(z)
-        rec_mu, rec_logvar, z_rec, rec_rec = model.forward(rec.detach())
-        fake_mu, fake_logvar, z_fake, rec_fake = model.forward(fake.detach())
+        # passes that share their weights and differ only in the input run as one batch where that fills the
+        # chip better (BatchNorm statistics, running updates and random draws per pass, as in the reference)
+        pair = self.pair and hasattr(model, "pair_ready") and model.pair_ready()
+        nb = real_batch.shape[0]
+        if pair:
+            mu2, logvar2, _, (rec_rec, rec_fake) = model.forward_pair(rec.detach(), fake.detach())     # :266-267
+            kl2 = ops.kl_per_sample(mu2, logvar2)
+            kl_rec, kl_fake = kl2[:nb], kl2[nb:]
+        else:
+            rec_mu, rec_logvar, z_rec, rec_rec = model.forward(rec.detach())
+            fake_mu, fake_logvar, z_fake, rec_fake = model.forward(fake.detach())
+            kl_rec, kl_fake = ops.kl_per_sample(rec_mu, rec_logvar), ops.kl_per_sample(fake_mu, fake_logvar)
         # per-sample terms (:260-275); `rec` is NOT detached in the last one (:275)
         lossE, se = ops.sintro_loss_e(
             ops.sse_per_sample(real_batch, rec), ops.kl_per_sample(real_mu, real_logvar),
-            ops.sse_per_sample(fake, rec_fake), ops.kl_per_sample(fake_mu, fake_logvar),
-            ops.sse_per_sample(rec, rec_rec), ops.kl_per_sample(rec_mu, rec_logvar), scale, br, bn, bk)
+            ops.sse_per_sample(fake, rec_fake), kl_fake,
+            ops.sse_per_sample(rec, rec_rec), kl_rec, scale, br, bn, bk)
         self.opt_e.zero_grad()
         lossE.backward()
         self.sync.average_and_step(self.opt_e)       # multi-GPU: exchange + update run beside the next two decodes
@@ -174,18 +186,26 @@ class SoftIntroStep:
             p.requires_grad = False
         for p in model.decoder.parameters():
             p.requires_grad = True
-        fake = model.decode(noise_batch)
-        rec = model.decode(z)
-        self.sync.wait()                             # the encoder update is complete from here on
-        rec_mu, rec_logvar = model.encode(rec)
-        z_rec = model.reparameterize(rec_mu, rec_logvar)
-        fake_mu, fake_logvar = model.encode(fake)
-        z_fake = model.reparameterize(fake_mu, fake_logvar)
-        rec_rec = model.decode(z_rec.detach())
-        rec_fake = model.decode(z_fake.detach())
+        if pair:
+            fake, rec = model.decode_pair(noise_batch, z)                                   # :297-298
+            self.sync.wait()                         # the encoder update is complete from here on
+            mu2, logvar2, z2 = model.encode_reparam_pair(rec, fake)                          # :304-308
+            rec_rec, rec_fake = model.decode_pair(z2.detach())                               # :310-311
+            kl2 = ops.kl_per_sample(mu2, logvar2)
+            kl_rec, kl_fake = kl2[:nb], kl2[nb:]
+        else:
+            fake = model.decode(noise_batch)
+            rec = model.decode(z)
+            self.sync.wait()                         # the encoder update is complete from here on
+            rec_mu, rec_logvar = model.encode(rec)
+            z_rec = model.reparameterize(rec_mu, rec_logvar)
+            fake_mu, fake_logvar = model.encode(fake)
+            z_fake = model.reparameterize(fake_mu, fake_logvar)
+            rec_rec = model.decode(z_rec.detach())
+            rec_fake = model.decode(z_fake.detach())
+            kl_rec, kl_fake = ops.kl_per_sample(rec_mu, rec_logvar), ops.kl_per_sample(fake_mu, fake_logvar)
         lossD, sd = ops.sintro_loss_d(
-            ops.sse_per_sample(real_batch, rec), ops.kl_per_sample(rec_mu, rec_logvar),
-            ops.kl_per_sample(fake_mu, fake_logvar), ops.sse_per_sample(rec.detach(), rec_rec),
+            ops.sse_per_sample(real_batch, rec), kl_rec, kl_fake, ops.sse_per_sample(rec.detach(), rec_rec),
             ops.sse_per_sample(fake.detach(), rec_fake), scale, br, bk, gr)
         self.opt_d.zero_grad()
         lossD.backward()

@@ -84,7 +84,10 @@ class CpuCheckerBackend:
         s = a + b
         return dout * torch.where(s > 0, torch.ones_like(s), torch.full_like(s, slope))
 
-    def bn_stats(self, y, running_mean, running_var, nbt, momentum):
+    def bn_stats(self, y, running_mean, running_var, nbt, momentum, groups=1):
+        if groups > 1:          # one statistics pair and one running update per consecutive part of the batch
+            parts = [self.bn_stats(yg, running_mean, running_var, nbt, momentum) for yg in y.chunk(groups)]
+            return torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts])
         mean = y.mean(dim=(0, 2, 3, 4))
         var = y.var(dim=(0, 2, 3, 4), unbiased=False)
         if running_mean is not None:
@@ -109,10 +112,31 @@ class CpuCheckerBackend:
         return h
 
     def bn_act_fwd(self, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps):
+        if mean.dim() == 2:     # grouped: statistics (groups, C)
+            G = mean.shape[0]
+            ch = lambda t: t.chunk(G) if t is not None else [None] * G
+            return torch.cat([self._tail(yg, mean[g], var[g], gamma, beta, rg, kg, p, slope, pool, eps)
+                              for g, (yg, rg, kg) in enumerate(zip(ch(y), ch(res), ch(keep)))])
         return self._tail(y, mean, var, gamma, beta, res, keep, p, slope, pool, eps)
 
     def bn_act_bwd(self, dout, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps, want_affine, want_res,
                    dgamma_out=None, dbeta_out=None):
+        if mean.dim() == 2:
+            G = mean.shape[0]
+            ch = lambda t: t.chunk(G) if t is not None else [None] * G
+            parts = [self.bn_act_bwd(dg, yg, mean[g], var[g], gamma, beta, rg, kg, p, slope, pool, eps, want_affine,
+                                     want_res)
+                     for g, (dg, yg, rg, kg) in enumerate(zip(ch(dout), ch(y), ch(res), ch(keep)))]
+            dy = torch.cat([q[0] for q in parts])
+            dres = torch.cat([q[3] for q in parts]) if parts[0][3] is not None else None
+            dg_ = sum(q[1] for q in parts) if want_affine else None
+            db_ = sum(q[2] for q in parts) if want_affine else None
+            if want_affine and dgamma_out is not None:
+                with torch.no_grad():
+                    dgamma_out += dg_
+                    dbeta_out += db_
+                return dy, dgamma_out, dbeta_out, dres
+            return dy, dg_, db_, dres
         # differentiate THROUGH the batch statistics, as training-mode BatchNorm does
         with torch.enable_grad():
             yy = y.detach().requires_grad_(True)

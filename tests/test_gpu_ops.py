@@ -360,6 +360,60 @@ def test_bn_act_fwd_bwd(B, c, dims, n, slope, pool, use_res, p):
     check(out_e, O.bn_act(y, gamma, beta, rm2, rv2, slope, pool, res, None, 0.0, False), "eval fwd")
 
 
+@pytest.mark.parametrize("c,dims,n,groups,pool,use_res,p", [
+    (64, (8, 12, 8), 4, 2, 1, False, 0.25), (256, (10, 12, 10), 4, 2, 1, True, 0.0), (128, (20, 24, 20), 4, 2, 2, False, 0.0),
+    (8, (4, 6, 4), 6, 3, 2, True, 0.35), (6, (4, 6, 4), 4, 2, 1, True, 0.0), (12, (4, 4, 4), 2, 2, 2, False, 0.0),
+    (8, (64, 130, 128), 2, 2, 1, False, 0.0),          # partial rows folded per group
+])
+def test_bn_grouped_equals_one_call_per_part(B, c, dims, n, groups, pool, use_res, p):
+    """The grouped BatchNorm operators (a batch made of `groups` passes of the reference: statistics per part,
+    running statistics updated part after part, affine gradients summed over the parts) against the same
+    operators called once per part -- bit for bit, same kernels per part -- and the statistics against torch."""
+    gen = torch.Generator().manual_seed(c + pool + groups)
+    y = rnd(gen, n, c, *dims) * 2 + torch.arange(n).view(n, 1, 1, 1, 1).float()      # parts differ in mean
+    gamma, beta = 1 + 0.3 * rnd(gen, c), 0.2 * rnd(gen, c)
+    res = rnd(gen, n, c, *dims) if use_res else None
+    odims = tuple(d // pool for d in dims)
+    keep = (torch.rand(n, c, *odims, generator=gen) >= p).to(torch.uint8) if p > 0 else None
+    dout = rnd(gen, n, c, *odims)
+    yd, gd, bd, rd, kd, dd = dev(y), dev(gamma), dev(beta), dev(res), dev(keep), dev(dout)
+    per = n // groups
+    part = lambda t, g: None if t is None else t[g * per:(g + 1) * per]
+    # statistics
+    rm, rv, nbt = dev(rnd(gen, c)), dev(torch.rand(c, generator=gen) + 0.5), dev(torch.tensor(3))
+    rm1, rv1, nbt1 = rm.clone(), rv.clone(), nbt.clone()
+    mean, var = B.bn_stats(yd, rm, rv, nbt, 0.1, groups)
+    assert mean.shape == (groups, c) and int(nbt) == 3 + groups
+    for g in range(groups):
+        m1, v1 = B.bn_stats(part(yd, g), rm1, rv1, nbt1, 0.1)
+        assert torch.equal(mean[g], m1) and torch.equal(var[g], v1), g
+        check(mean[g], part(y, g).double().mean(dim=(0, 2, 3, 4)).float(), "mean", floor=1e-6)
+        check(var[g], part(y, g).double().var(dim=(0, 2, 3, 4), unbiased=False).float(), "var")
+    assert torch.equal(rm, rm1) and torch.equal(rv, rv1) and int(nbt1) == int(nbt)
+    # forward
+    out = B.bn_act_fwd(yd, mean, var, gd, bd, rd, kd, p, 0.2, pool, 1e-5)
+    for g in range(groups):
+        o1 = B.bn_act_fwd(part(yd, g), mean[g], var[g], gd, bd, part(rd, g), part(kd, g), p, 0.2, pool, 1e-5)
+        assert torch.equal(part(out, g), o1), g
+    # backward, affine gradients accumulated into buffers that already hold something
+    acc_g, acc_b = dev(rnd(gen, c)), dev(rnd(gen, c))
+    acc_g0, acc_g1, acc_b1 = acc_g.clone(), acc_g.clone(), acc_b.clone()
+    dy, _, _, dres = B.bn_act_bwd(dd, yd, mean, var, gd, bd, rd, kd, p, 0.2, pool, 1e-5, True, use_res, acc_g, acc_b)
+    for g in range(groups):
+        dy1, _, _, dres1 = B.bn_act_bwd(part(dd, g), part(yd, g), mean[g], var[g], gd, bd, part(rd, g), part(kd, g),
+                                        p, 0.2, pool, 1e-5, True, use_res, acc_g1, acc_b1)
+        assert torch.equal(part(dy, g), dy1), g
+        if use_res:
+            assert torch.equal(part(dres, g), dres1), g
+    assert torch.equal(acc_g, acc_g1) and torch.equal(acc_b, acc_b1)
+    dy2, dg2, db2, _ = B.bn_act_bwd(dd, yd, mean, var, gd, bd, rd, kd, p, 0.2, pool, 1e-5, True, False)
+    assert torch.equal(dy2, dy)
+    check(dg2, acc_g - acc_g0, "dgamma returned vs accumulated", tol=1e-4)
+    import siv._lib as L
+    with pytest.raises(L.SivError):                               # batch not a multiple of the groups
+        B.bn_stats(torch.zeros(groups + 1, c, 2, 2, 2, device="cuda"), None, None, None, 0.1, groups)
+
+
 def test_act_dropout(B):
     gen = torch.Generator().manual_seed(11)
     x = rnd(gen, 2, 1, 6, 7, 5)
