@@ -1804,6 +1804,17 @@ static int up_dgrad_parts(long nblk_total, int Cout, long dx_elems) {
     const long slots = 512;
     const int ngroup = nchunk / 4;
     if (nblk_total * 5 < slots * 2 && ngroup % 2 == 0) return ngroup % 4 == 0 ? 4 : 2;
+    // one round that is 40..100 % full (the same layer on a merged batch of two passes): the number of parts
+    // that shortens the launch by at least a fifth -- rounds of blocks x the length of a block
+    if (nblk_total <= slots && ngroup % 2 == 0 && 2 * dx_elems * 4 <= (96L << 20)) {
+        int best = 1;
+        long best_cost = 4;                                        // cost in quarters of an unsplit block
+        for (int p = 2; p <= (ngroup % 4 == 0 ? 4 : 2); p *= 2) {
+            const long cost = cdiv(nblk_total * p, slots) * (4 / p);
+            if (cost < best_cost && cost * 5 <= 4 * 4 && (long)p * dx_elems * 4 <= (96L << 20)) best = p, best_cost = cost;
+        }
+        if (best > 1) return best;
+    }
     const long rounds = cdiv(nblk_total, slots);
     if (nblk_total > slots && rounds <= 3 && nblk_total * 10 <= (rounds * 10 - 4) * slots
         && cdiv(2 * nblk_total, slots) < 2 * rounds && ngroup % 2 == 0 && 2 * dx_elems * 4 <= (96L << 20))

@@ -533,16 +533,22 @@ class HipBackend:
     def _groups_of(mean) -> int:
         return 1 if mean.dim() == 1 else int(mean.shape[0])
 
-    def bn_act_fwd(self, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps):
+    def bn_act_fwd(self, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps, out=None):
         """``mean`` / ``var`` of shape (groups, C) select the grouped operator (one set of statistics per
-        consecutive part of the batch)."""
+        consecutive part of the batch).  ``out``: write the result there (a dense channels-last tensor of the
+        output shape, e.g. a batch slice of a larger buffer) instead of into a new tensor."""
         self._check_dev(y, mean, var, gamma, beta, res, keep)
         groups = self._groups_of(mean)
         mean, var = mean.contiguous(), var.contiguous()
         y = cl(y)
         res = cl(res) if res is not None else None
         N, C, D, H, W = y.shape
-        out = empty_cl((N, C, D // pool, H // pool, W // pool), y)
+        oshape = (N, C, D // pool, H // pool, W // pool)
+        if out is None:
+            out = empty_cl(oshape, y)
+        elif (tuple(out.shape) != oshape or out.dtype != torch.float32 or out.device != y.device
+              or not out.is_contiguous(memory_format=CL3D)):
+            raise _lib.SivError("bn_act_fwd: `out` must be a dense channels-last fp32 tensor of the output shape")
         if keep is not None:
             keep = cl(keep)
             assert keep.dtype == torch.uint8 and keep.shape == out.shape

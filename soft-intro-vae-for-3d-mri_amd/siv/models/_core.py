@@ -92,13 +92,14 @@ class BuildingBlock(_ResBlockBase):
             nn.BatchNorm3d(out_ch),
         )
 
-    def forward(self, x, groups: int = 1):
+    def forward(self, x, groups: int = 1, out=None):
         """``groups`` > 1: ``x`` is that many passes of the reference concatenated on the batch axis
-        (BatchNorm statistics per part)."""
+        (BatchNorm statistics per part).  ``out``: destination of the block's output (a dense tensor of its
+        shape, e.g. a batch slice of the buffer a paired pass merges its members in)."""
         c1, b1, _, _, c2, b2 = self.block
         s = self.variant.slope
         h = ops.conv_bn_act(x, c1, b1, s, pool=self.stride, train=self.training, groups=groups)
-        return ops.conv_bn_act(h, c2, b2, s, residual=self._res(x), train=self.training, groups=groups)
+        return ops.conv_bn_act(h, c2, b2, s, residual=self._res(x), train=self.training, groups=groups, out=out)
 
 
 class UpsampleBuildingkBlock(_ResBlockBase):
@@ -198,14 +199,22 @@ class ResNetEncoder(nn.Module):
                 first_merged = i
                 break
             vox //= blk.stride ** 3
-        hs = []
+        hs, into = [], None
         for g, x in enumerate(xs):
             with cur.member(g):
                 h = self._stem(x)
-                for blk in blocks[:first_merged]:
+                for blk in blocks[:max(first_merged - 1, 0)]:
                     h = blk(h)
+                if first_merged > 0:
+                    # the last per-member block writes straight into its slice of the merged batch
+                    blk = blocks[first_merged - 1]
+                    if into is None:
+                        n, d = h.shape[0], [int(v) // blk.stride for v in h.shape[2:]]
+                        into = torch.empty((n * len(xs), blk.block[4].out_channels, *d), device=h.device,
+                                           dtype=torch.float32, memory_format=torch.channels_last_3d)
+                    h = blk(h, out=None if into is None else into[g * h.shape[0]:(g + 1) * h.shape[0]])
             hs.append(h)
-        h = torch.cat(hs)
+        h = ops.merge_members(hs, into)
         for blk in blocks[first_merged:]:
             h = blk(h, groups=len(xs))
         return h
@@ -315,8 +324,9 @@ class ResNetDecoder(nn.Module):
         for blk in body[:n_merged]:
             h = blk(h, groups=members)
         outs = []
+        parts = ops.split_members(h, members)
         for g in range(members):
-            hg = h[g * per:(g + 1) * per]
+            hg = parts[g]
             for blk in body[n_merged:]:
                 hg = blk(hg)
             with cur.member(g):

@@ -233,7 +233,7 @@ def add_act(a, b, slope: float):
 
 class _BnAct(Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, res, keep, bn, p, slope, pool, train, stats=None, groups=1):
+    def forward(ctx, y, gamma, beta, res, keep, bn, p, slope, pool, train, stats=None, groups=1, out=None):
         B = get_backend()
         if train and stats is not None:
             mean, var = stats          # already computed (and the running statistics updated)
@@ -247,7 +247,9 @@ class _BnAct(Function):
                                    BN_MOMENTUM if bn.momentum is None else bn.momentum)
         else:
             mean, var = bn.running_mean, bn.running_var
-        out = B.bn_act_fwd(y, mean, var, gamma, beta, res, keep, p, slope, pool, bn.eps)
+        # `out` (an Into holder): the result is written into that tensor, e.g. a batch slice of a larger buffer
+        out = B.bn_act_fwd(y, mean, var, gamma, beta, res, keep, p, slope, pool, bn.eps,
+                           **({"out": out.t} if out is not None else {}))
         ctx.save_for_backward(y, mean, var, gamma, beta, res, keep)
         ctx.cfg = (p, slope, pool, bn.eps, train)
         ctx.g_buf, ctx.b_buf = _grad_buf(gamma), _grad_buf(beta)
@@ -272,11 +274,84 @@ class _BnAct(Function):
         if not ctx.needs_input_grad[0]:
             dy = None
         return (dy, dg if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None,
-                dres, None, None, None, None, None, None, None, None)
+                dres, None, None, None, None, None, None, None, None, None)
+
+
+class Into:
+    """Holder that hands a destination tensor to an operator without making it an autograd input."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+class _Merge(Function):
+    """The members of a paired pass as one batch.  When every member already lives in its batch slice of
+    ``into.t`` (the operators that produced them were given those slices as their destination) nothing is
+    copied; backward hands each member its slice of the gradient."""
+
+    @staticmethod
+    def forward(ctx, into, *hs):
+        big = into.t
+        per = hs[0].shape[0]
+        ctx.per = per
+        for g, h in enumerate(hs):
+            dst = big[g * per:(g + 1) * per]
+            if h.data_ptr() != dst.data_ptr() or h.stride() != dst.stride():
+                dst.copy_(h)
+        return big
+
+    @staticmethod
+    def backward(ctx, grad):
+        per = ctx.per
+        n = grad.shape[0] // per
+        return (None,) + tuple(grad[g * per:(g + 1) * per] for g in range(n))
+
+
+def merge_members(hs, into=None):
+    """Concatenation of the member tensors ``hs`` on the batch axis; ``into``: the buffer they were written
+    into slice by slice (then no copy is made)."""
+    if into is None:
+        return torch.cat(list(hs))
+    return _Merge.apply(Into(into), *hs)
+
+
+class _Split(Function):
+    """Batch slices of a merged tensor, one per member; backward assembles the members' gradients in one
+    buffer (a missing gradient counts as zero)."""
+
+    @staticmethod
+    def forward(ctx, x, members):
+        per = x.shape[0] // members
+        ctx.cfg = (per, members)
+        base = x.detach()
+        return tuple(base[g * per:(g + 1) * per] for g in range(members))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        per, members = ctx.cfg
+        live = [g for g in grads if g is not None]
+        if not live:
+            return None, None
+        ref = live[0]
+        full = torch.empty((per * members,) + tuple(ref.shape[1:]), dtype=ref.dtype, device=ref.device,
+                           memory_format=torch.channels_last_3d if ref.dim() == 5 else torch.contiguous_format)
+        for g, gr in enumerate(grads):
+            dst = full[g * per:(g + 1) * per]
+            if gr is None:
+                dst.zero_()
+            else:
+                dst.copy_(gr)
+        return full, None
+
+
+def split_members(x, members: int):
+    """The ``members`` equal batch slices of ``x`` (views; no copy in the forward pass)."""
+    return _Split.apply(x, members)
 
 
 def bn_act(y, bn, slope: float, pool: int = 1, residual=None, keep=None, p: float = 0.0,
-           train: bool = True, stats=None, groups: int = 1):
+           train: bool = True, stats=None, groups: int = 1, out=None):
     """BatchNorm3d (parameters/buffers of module ``bn``) -> [+residual] -> LeakyReLU(slope)
     -> AvgPool3d(pool) -> dropout(keep, p) as one fused pass.  ``stats`` = (mean, biased var) when
     the producer of ``y`` already computed the batch statistics.  ``groups`` > 1 (training mode): the batch is
@@ -285,22 +360,22 @@ def bn_act(y, bn, slope: float, pool: int = 1, residual=None, keep=None, p: floa
     if pool not in (1, 2):
         raise ValueError(f"only stride/pool 1 or 2 is supported (got {pool})")
     return _BnAct.apply(y, bn.weight, bn.bias, residual, keep, bn, p, slope, pool, train, stats,
-                        groups if train else 1)
+                        groups if train else 1, Into(out) if out is not None else None)
 
 
 def conv_bn_act(x, conv, bn, slope: float, ups: int = 1, pool: int = 1, residual=None, keep=None,
-                p: float = 0.0, train: bool = True, groups: int = 1):
+                p: float = 0.0, train: bool = True, groups: int = 1, out=None):
     """conv3d_k3 (parameters of module ``conv``) followed by ``bn_act``.  In training mode the
     convolution call also produces the BatchNorm batch statistics (one set); with ``groups`` > 1 the
     statistics are per part of the batch and come from a pass of their own."""
     if train and groups > 1:
         y = _Conv3dK3.apply(x, conv.weight, conv.bias, ups, None)
-        return bn_act(y, bn, slope, pool, residual, keep, p, True, None, groups)
+        return bn_act(y, bn, slope, pool, residual, keep, p, True, None, groups, out)
     if train:
         y, mean, var = _Conv3dK3.apply(x, conv.weight, conv.bias, ups, bn)
-        return bn_act(y, bn, slope, pool, residual, keep, p, True, (mean, var))
+        return bn_act(y, bn, slope, pool, residual, keep, p, True, (mean, var), 1, out)
     y = _Conv3dK3.apply(x, conv.weight, conv.bias, ups, None)
-    return bn_act(y, bn, slope, pool, residual, keep, p, False)
+    return bn_act(y, bn, slope, pool, residual, keep, p, False, None, 1, out)
 
 
 class _Conv1BnAct(Function):

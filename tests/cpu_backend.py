@@ -111,7 +111,12 @@ class CpuCheckerBackend:
             h = h * keep.float() * (1.0 / (1.0 - p))
         return h
 
-    def bn_act_fwd(self, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps):
+    def bn_act_fwd(self, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps, out=None):
+        if out is not None:     # destination given by the caller
+            # written behind autograd's back, as a kernel writes through a raw pointer (the destination is a
+            # slice of a buffer whose other slices are outputs of earlier calls)
+            out.data.copy_(self.bn_act_fwd(y, mean, var, gamma, beta, res, keep, p, slope, pool, eps))
+            return out
         if mean.dim() == 2:     # grouped: statistics (groups, C)
             G = mean.shape[0]
             ch = lambda t: t.chunk(G) if t is not None else [None] * G
