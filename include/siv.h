@@ -318,6 +318,27 @@ int siv_bn_act_bwd_grouped(const float* dout, const float* y, const float* mean,
                            float* dy, float* dgamma, float* dbeta, float* dresidual, int accumulate,
                            int N, int D, int H, int W, int C, int groups,
                            void* ws, size_t ws_bytes, siv_stream_t stream);
+/* bf16 activation storage inside the BatchNorm passes (no reference counterpart: the reference trains in fp32,
+ * utils/my_trainer.py:242-325; this is the "bf16 activations" of the 160x192x160 configuration).  The two
+ * tensors a conv -> BatchNorm -> activation layer keeps for its backward pass are the convolution output y (for
+ * the BatchNorm backward) and the activated output (the next convolution's input, for its weight gradient).
+ * siv_bn_act_fwd_bf16 is siv_bn_act_fwd_grouped that ALSO writes bf16 copies (round-to-nearest-even) of y
+ * (y_bf16, NULL = none) and of out (out_bf16, NULL = none) in the same pass, so that the fp32 tensors need not
+ * be kept and no separate conversion pass reads them again; siv_bn_act_bwd_bf16 is siv_bn_act_bwd_grouped
+ * reading y from its bf16 copy (half the bytes in both of its passes).  Arithmetic is fp32 throughout.  Both
+ * need the float4 kernels: siv_bn_act_bf16_supported(C) (C = 4..1024, a power of two), 16-byte aligned tensors. */
+int siv_bn_act_bf16_supported(int C);
+int siv_bn_act_fwd_bf16(const float* y, const float* mean, const float* var,
+                        const float* gamma, const float* beta, const float* residual,
+                        const uint8_t* keep, float p, float slope, int pool, float eps,
+                        float* out, void* y_bf16, void* out_bf16, int N, int D, int H, int W, int C,
+                        int groups, siv_stream_t stream);
+int siv_bn_act_bwd_bf16(const float* dout, const void* y_bf16, const float* mean, const float* var,
+                        const float* gamma, const float* beta, const float* residual,
+                        const uint8_t* keep, float p, float slope, int pool, float eps,
+                        float* dy, float* dgamma, float* dbeta, float* dresidual, int accumulate,
+                        int N, int D, int H, int W, int C, int groups,
+                        void* ws, size_t ws_bytes, siv_stream_t stream);
 /* out = dropout(act(x)) without normalisation: the decoder tail nn.ReLU + nn.Dropout(0.35)
  * of models/models.py:139-140, and its backward (dx = dout * keep/(1-p) * act'(x)). */
 int siv_act_dropout_fwd(const float* x, const uint8_t* keep, float p, float slope,

@@ -409,6 +409,22 @@ __device__ __forceinline__ float4 keep4(const uint8_t* __restrict__ keep, long q
                        k.w ? v.w * dscale : 0.f);
 }
 
+// four channels held as bf16 (8 bytes): the storage format of activations kept for the backward pass
+__device__ __forceinline__ void st_bf4(uint16_t* __restrict__ p, long q, float4 v) {
+    reinterpret_cast<uint2*>(p)[q] = make_uint2(bf16_rne(v.x) | (bf16_rne(v.y) << 16), bf16_rne(v.z) | (bf16_rne(v.w) << 16));
+}
+__device__ __forceinline__ float4 ld_bf4(const uint16_t* __restrict__ p, long q) {
+    const uint2 u = reinterpret_cast<const uint2*>(p)[q];
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+// the saved convolution output: fp32, or (YBF) its bf16 copy
+template <bool YBF>
+__device__ __forceinline__ float4 ld_y(const float* __restrict__ y, long q) {
+    if constexpr (YBF) return ld_bf4(reinterpret_cast<const uint16_t*>(y), q);
+    else return ld4(y, q);
+}
+
 // per-thread coefficients of its four channels
 struct Coef {
     float4 a, b, mean, invstd;
@@ -501,12 +517,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd_v(const float* __restrict__ y,
                                                     const float* __restrict__ res,
                                                     const uint8_t* __restrict__ keep, float p,
                                                     float slope, float eps, float* __restrict__ out,
-                                                    long OQ, PoolGeom g) {
+                                                    long OQ, PoolGeom g, uint16_t* __restrict__ ybf,
+                                                    uint16_t* __restrict__ obf) {
+    // ybf / obf (optional): bf16 copies of the input y and of the output, written in the same pass -- what the
+    // backward pass keeps when activations are stored as bf16
     {   // group blockIdx.y: OQ output quads (8 OQ input quads when pooled), its own statistics
         const long go = (long)blockIdx.y * OQ * 4, gi = go * (POOL == 2 ? 8 : 1);
         y += gi, out += go, mean += blockIdx.y * g.C4 * 4, var += blockIdx.y * g.C4 * 4;
         if (res) res += gi;
         if (keep) keep += go;
+        if (ybf) ybf += gi;
+        if (obf) obf += go;
     }
     const Coef k = load_coef(mean, var, gamma, beta, eps, threadIdx.x % g.C4);
     const float dscale = 1.0f / (1.0f - p);
@@ -527,13 +548,18 @@ __global__ __launch_bounds__(256) void bn_act_fwd_v(const float* __restrict__ y,
             }
             st4(out, q, o0);
             st4(out, q + T, o1);
+            if (ybf) st_bf4(ybf, q, y0), st_bf4(ybf, q + T, y1);
+            if (obf) st_bf4(obf, q, o0), st_bf4(obf, q + T, o1);
         }
         for (; q < OQ; q += T) {
-            float4 z = fma4(ld4(y, q), k.a, k.b);
+            const float4 y0 = ld4(y, q);
+            float4 z = fma4(y0, k.a, k.b);
             if (res) z = z + ld4(res, q);
             float4 o = leaky4(z, slope);
             if (keep) o = keep4(keep, q, o, dscale);
             st4(out, q, o);
+            if (ybf) st_bf4(ybf, q, y0);
+            if (obf) st_bf4(obf, q, o);
         }
     } else {
         for (; q < OQ; q += T) {
@@ -549,9 +575,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_v(const float* __restrict__ y,
                 if (res) z = z + ld4(res, j0 + (e >> 2) * sd + ((e >> 1) & 1) * shh + (e & 1) * sw);
                 acc = acc + leaky4(z, slope);
             }
+            if (ybf)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) st_bf4(ybf, j0 + (e >> 2) * sd + ((e >> 1) & 1) * shh + (e & 1) * sw, v[e]);
             float4 o = acc * f4(0.125f);
             if (keep) o = keep4(keep, q, o, dscale);
             st4(out, q, o);
+            if (obf) st_bf4(obf, q, o);
         }
     }
 }
@@ -566,7 +596,7 @@ __device__ __forceinline__ float4 bwd_dz(float4 g, float4 yv, const float* __res
 }
 
 // APPLY = 0: per-block partial sums of dz and dz*xhat.  APPLY = 1: dy (and dres) from the sums.
-template <int POOL, int APPLY>
+template <int POOL, int APPLY, bool YBF = false>
 __global__ __launch_bounds__(256) void bn_bwd_v(const float* __restrict__ dout,
                                                 const float* __restrict__ y,
                                                 const float* __restrict__ mean,
@@ -581,7 +611,7 @@ __global__ __launch_bounds__(256) void bn_bwd_v(const float* __restrict__ dout,
     __shared__ float4 sh[APPLY ? 1 : 512];
     {   // group blockIdx.y (see bn_act_fwd_v): its own statistics, sums and partial rows
         const long go = (long)blockIdx.y * OQ * 4, gi = go * (POOL == 2 ? 8 : 1);
-        dout += go, y += gi, mean += blockIdx.y * C, var += blockIdx.y * C;
+        dout += go, y += YBF ? gi / 2 : gi, mean += blockIdx.y * C, var += blockIdx.y * C;   // y: bf16 = half a float each
         if (keep) keep += go;
         if (res) res += gi;
         if (APPLY) {
@@ -605,7 +635,7 @@ __global__ __launch_bounds__(256) void bn_bwd_v(const float* __restrict__ dout,
     if (POOL == 1) {
         for (; q + T < OQ; q += 2 * T) {
             float4 g0 = ld4(dout, q), g1 = ld4(dout, q + T);
-            const float4 y0 = ld4(y, q), y1 = ld4(y, q + T);
+            const float4 y0 = ld_y<YBF>(y, q), y1 = ld_y<YBF>(y, q + T);
             if (keep) {
                 g0 = keep4(keep, q, g0, dscale);
                 g1 = keep4(keep, q + T, g1, dscale);
@@ -630,7 +660,7 @@ __global__ __launch_bounds__(256) void bn_bwd_v(const float* __restrict__ dout,
             float4 g0 = ld4(dout, q);
             if (keep) g0 = keep4(keep, q, g0, dscale);
             float4 x0;
-            const float4 d0 = bwd_dz(g0, ld4(y, q), res, q, k, slope, &x0);
+            const float4 d0 = bwd_dz(g0, ld_y<YBF>(y, q), res, q, k, slope, &x0);
             if (APPLY) {
                 st4(dy, q, k.a * (d0 - k1 - x0 * k2));
                 if (dres) st4(dres, q, d0);
@@ -648,7 +678,7 @@ __global__ __launch_bounds__(256) void bn_bwd_v(const float* __restrict__ dout,
             go = go * f4(0.125f);
             float4 v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = ld4(y, j0 + (e >> 2) * sd + ((e >> 1) & 1) * shh + (e & 1) * sw);
+            for (int e = 0; e < 8; ++e) v[e] = ld_y<YBF>(y, j0 + (e >> 2) * sd + ((e >> 1) & 1) * shh + (e & 1) * sw);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const long j = j0 + (e >> 2) * sd + ((e >> 1) & 1) * shh + (e & 1) * sw;
@@ -800,11 +830,12 @@ int bn_bwd_finalize_launch(const float* part, int nblk, int C, float* sums, floa
 }
 }  // namespace siv
 
-extern "C" int siv_bn_act_fwd_grouped(const float* y, const float* mean, const float* var,
-                                      const float* gamma, const float* beta, const float* residual,
-                                      const uint8_t* keep, float p, float slope, int pool, float eps,
-                                      float* out, int N, int D, int H, int W, int C, int groups,
-                                      siv_stream_t stream) {
+// ybf / obf: optional bf16 copies of y and of the output (float4 kernels only)
+static int bn_act_fwd_impl(const float* y, const float* mean, const float* var,
+                           const float* gamma, const float* beta, const float* residual,
+                           const uint8_t* keep, float p, float slope, int pool, float eps,
+                           float* out, int N, int D, int H, int W, int C, int groups,
+                           uint16_t* ybf, uint16_t* obf, siv_stream_t stream) {
     SIV_CHECK_ARG(y && mean && var && gamma && beta && out, "bn_act_fwd: null pointer");
     SIV_CHECK_ARG(N > 0 && D > 0 && H > 0 && W > 0 && C > 0, "bn_act_fwd: bad shape");
     SIV_CHECK_ARG(groups > 0 && groups <= 65535 && N % groups == 0,
@@ -821,15 +852,18 @@ extern "C" int siv_bn_act_fwd_grouped(const float* y, const float* mean, const f
         ((uintptr_t)keep & 3) == 0) {
         const PoolGeom g = {D / pool, H / pool, W / pool, H, W, C / 4, ilog2(C / 4)};
         const long OQ = total / 4;
+        SIV_CHECK_ARG((((uintptr_t)ybf | (uintptr_t)obf) & 7) == 0, "bn_act_fwd: the bf16 copies must be 8-byte aligned");
         if (pool == 1)
             bn_act_fwd_v<1><<<dim3(vec_grid_apply(OQ, 4), groups), 256, 0, s>>>(y, mean, var, gamma, beta, residual,
-                                                                             keep, p, slope, eps, out, OQ, g);
+                                                                             keep, p, slope, eps, out, OQ, g, ybf, obf);
         else
             bn_act_fwd_v<2><<<dim3(vec_grid_apply(OQ, 1), groups), 256, 0, s>>>(y, mean, var, gamma, beta, residual,
-                                                                             keep, p, slope, eps, out, OQ, g);
+                                                                             keep, p, slope, eps, out, OQ, g, ybf, obf);
         SIV_CHECK_LAUNCH("bn_act_fwd");
         return SIV_OK;
     }
+    SIV_CHECK_ARG(!ybf && !obf, "bn_act_fwd: bf16 copies need C = 4..1024 a power of two and 16-byte aligned tensors "
+                                "(ask siv_bn_act_bf16_supported)");
     const long in_total = (long)Ng * D * H * W * C;
     for (int gi = 0; gi < groups; ++gi) {                         // scalar kernels: one launch per group
         const float* yg = y + gi * in_total;
@@ -845,6 +879,23 @@ extern "C" int siv_bn_act_fwd_grouped(const float* y, const float* mean, const f
     }
     return SIV_OK;
 }
+extern "C" int siv_bn_act_fwd_grouped(const float* y, const float* mean, const float* var,
+                                      const float* gamma, const float* beta, const float* residual,
+                                      const uint8_t* keep, float p, float slope, int pool, float eps,
+                                      float* out, int N, int D, int H, int W, int C, int groups,
+                                      siv_stream_t stream) {
+    return bn_act_fwd_impl(y, mean, var, gamma, beta, residual, keep, p, slope, pool, eps, out, N, D, H, W, C, groups,
+                           nullptr, nullptr, stream);
+}
+extern "C" int siv_bn_act_bf16_supported(int C) { return vec_channels(C) ? 1 : 0; }
+extern "C" int siv_bn_act_fwd_bf16(const float* y, const float* mean, const float* var,
+                                   const float* gamma, const float* beta, const float* residual,
+                                   const uint8_t* keep, float p, float slope, int pool, float eps,
+                                   float* out, void* y_bf16, void* out_bf16, int N, int D, int H, int W, int C,
+                                   int groups, siv_stream_t stream) {
+    return bn_act_fwd_impl(y, mean, var, gamma, beta, residual, keep, p, slope, pool, eps, out, N, D, H, W, C, groups,
+                           (uint16_t*)y_bf16, (uint16_t*)out_bf16, stream);
+}
 extern "C" int siv_bn_act_fwd(const float* y, const float* mean, const float* var,
                               const float* gamma, const float* beta, const float* residual,
                               const uint8_t* keep, float p, float slope, int pool, float eps,
@@ -853,12 +904,13 @@ extern "C" int siv_bn_act_fwd(const float* y, const float* mean, const float* va
                                   1, stream);
 }
 
-extern "C" int siv_bn_act_bwd_grouped(const float* dout, const float* y, const float* mean, const float* var,
-                                      const float* gamma, const float* beta, const float* residual,
-                                      const uint8_t* keep, float p, float slope, int pool, float eps,
-                                      float* dy, float* dgamma, float* dbeta, float* dresidual,
-                                      int accumulate, int N, int D, int H, int W, int C, int groups, void* ws,
-                                      size_t ws_bytes, siv_stream_t stream) {
+// ybf: y points at the bf16 copy of the convolution output (float4 kernels only)
+static int bn_act_bwd_impl(const float* dout, const float* y, bool ybf, const float* mean, const float* var,
+                           const float* gamma, const float* beta, const float* residual,
+                           const uint8_t* keep, float p, float slope, int pool, float eps,
+                           float* dy, float* dgamma, float* dbeta, float* dresidual,
+                           int accumulate, int N, int D, int H, int W, int C, int groups, void* ws,
+                           size_t ws_bytes, siv_stream_t stream) {
     SIV_CHECK_ARG(dout && y && mean && var && gamma && beta && dy, "bn_act_bwd: null pointer");
     SIV_CHECK_ARG(N > 0 && D > 0 && H > 0 && W > 0 && C > 0, "bn_act_bwd: bad shape");
     SIV_CHECK_ARG(groups > 0 && groups <= 65535 && N % groups == 0,
@@ -873,6 +925,7 @@ extern "C" int siv_bn_act_bwd_grouped(const float* dout, const float* y, const f
     const bool vec = vec_channels(C) && M < (1L << 31) && aligned16(dout) && aligned16(y) && aligned16(dy) &&
                      aligned16(residual) && aligned16(dresidual) && aligned16(mean) && aligned16(var) &&
                      aligned16(gamma) && aligned16(beta) && aligned16(ws) && ((uintptr_t)keep & 3) == 0;
+    SIV_CHECK_ARG(vec || !ybf, "bn_act_bwd: a bf16 y needs C = 4..1024 a power of two and 16-byte aligned tensors");
     const long OQ = (long)Ng * (D / pool) * (H / pool) * (W / pool) * (C / 4);   // loop extent of the float4 path
     const int nblk = vec ? vec_grid(OQ, pool == 1 ? 8 : 2) : stat_blocks(M);
     const size_t part_bytes = align256((size_t)groups * nblk * 2 * C * sizeof(float));
@@ -883,24 +936,26 @@ extern "C" int siv_bn_act_bwd_grouped(const float* dout, const float* y, const f
     if (vec) {
         const PoolGeom g = {D / pool, H / pool, W / pool, H, W, C / 4, ilog2(C / 4)};
         const float invM = 1.0f / (float)M;
+#define SIV_BWD_V(POOL, APPLY, GRID, ...)                                                        \
+    (ybf ? bn_bwd_v<POOL, APPLY, true><<<GRID, 256, 0, s>>>(__VA_ARGS__)                          \
+         : bn_bwd_v<POOL, APPLY, false><<<GRID, 256, 0, s>>>(__VA_ARGS__))
         if (pool == 1)
-            bn_bwd_v<1, 0><<<dim3(nblk, groups), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual, keep, p, slope,
-                                                              eps, nullptr, invM, OQ, g, C, part, nullptr, nullptr);
+            SIV_BWD_V(1, 0, dim3(nblk, groups), dout, y, mean, var, gamma, beta, residual, keep, p, slope, eps, nullptr,
+                      invM, OQ, g, C, part, nullptr, nullptr);
         else
-            bn_bwd_v<2, 0><<<dim3(nblk, groups), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual, keep, p, slope,
-                                                              eps, nullptr, invM, OQ, g, C, part, nullptr, nullptr);
+            SIV_BWD_V(2, 0, dim3(nblk, groups), dout, y, mean, var, gamma, beta, residual, keep, p, slope, eps, nullptr,
+                      invM, OQ, g, C, part, nullptr, nullptr);
         SIV_CHECK_LAUNCH("bn_act_bwd(partial)");
         const int nfold = fold_rows(part, nblk, 2 * C, s, groups);
         bn_bwd_finalize<<<(C + 3) / 4, 256, 0, s>>>(part, nfold, C, sums, dgamma, dbeta, accumulate, groups, nblk);
         SIV_CHECK_LAUNCH("bn_act_bwd(finalize)");
         if (pool == 1)
-            bn_bwd_v<1, 1><<<dim3(vec_grid_apply(OQ, 4), groups), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual,
-                                                                            keep, p, slope, eps, sums, invM, OQ, g, C,
-                                                                            nullptr, dy, dresidual);
+            SIV_BWD_V(1, 1, dim3(vec_grid_apply(OQ, 4), groups), dout, y, mean, var, gamma, beta, residual, keep, p, slope,
+                      eps, sums, invM, OQ, g, C, nullptr, dy, dresidual);
         else
-            bn_bwd_v<2, 1><<<dim3(vec_grid_apply(OQ, 1), groups), 256, 0, s>>>(dout, y, mean, var, gamma, beta, residual,
-                                                                            keep, p, slope, eps, sums, invM, OQ, g, C,
-                                                                            nullptr, dy, dresidual);
+            SIV_BWD_V(2, 1, dim3(vec_grid_apply(OQ, 1), groups), dout, y, mean, var, gamma, beta, residual, keep, p, slope,
+                      eps, sums, invM, OQ, g, C, nullptr, dy, dresidual);
+#undef SIV_BWD_V
         SIV_CHECK_LAUNCH("bn_act_bwd(apply)");
         return SIV_OK;
     }
@@ -931,6 +986,24 @@ extern "C" int siv_bn_act_bwd_grouped(const float* dout, const float* y, const f
         SIV_CHECK_LAUNCH("bn_act_bwd(apply)");
     }
     return SIV_OK;
+}
+extern "C" int siv_bn_act_bwd_grouped(const float* dout, const float* y, const float* mean, const float* var,
+                                      const float* gamma, const float* beta, const float* residual,
+                                      const uint8_t* keep, float p, float slope, int pool, float eps,
+                                      float* dy, float* dgamma, float* dbeta, float* dresidual,
+                                      int accumulate, int N, int D, int H, int W, int C, int groups, void* ws,
+                                      size_t ws_bytes, siv_stream_t stream) {
+    return bn_act_bwd_impl(dout, y, false, mean, var, gamma, beta, residual, keep, p, slope, pool, eps, dy, dgamma,
+                           dbeta, dresidual, accumulate, N, D, H, W, C, groups, ws, ws_bytes, stream);
+}
+extern "C" int siv_bn_act_bwd_bf16(const float* dout, const void* y_bf16, const float* mean, const float* var,
+                                   const float* gamma, const float* beta, const float* residual,
+                                   const uint8_t* keep, float p, float slope, int pool, float eps,
+                                   float* dy, float* dgamma, float* dbeta, float* dresidual,
+                                   int accumulate, int N, int D, int H, int W, int C, int groups, void* ws,
+                                   size_t ws_bytes, siv_stream_t stream) {
+    return bn_act_bwd_impl(dout, (const float*)y_bf16, true, mean, var, gamma, beta, residual, keep, p, slope, pool,
+                           eps, dy, dgamma, dbeta, dresidual, accumulate, N, D, H, W, C, groups, ws, ws_bytes, stream);
 }
 extern "C" int siv_bn_act_bwd(const float* dout, const float* y, const float* mean, const float* var,
                               const float* gamma, const float* beta, const float* residual,

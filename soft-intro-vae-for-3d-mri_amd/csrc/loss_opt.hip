@@ -234,11 +234,6 @@ __global__ __launch_bounds__(256) void axpby_k(float a, const float* __restrict_
 // ---- bf16 storage of tensors kept for the backward pass ---------------------------------
 // fp32 -> bf16 with round-to-nearest-even (NaN stays NaN), eight elements per thread and step
 // (32 bytes in, 16 bytes out); bf16 -> fp32 is exact.
-__device__ __forceinline__ uint32_t bf16_rne(float f) {
-    const uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;        // quiet NaN
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
 __global__ __launch_bounds__(256) void f32_to_bf16_k(const float* __restrict__ x, uint16_t* __restrict__ h, long n) {
     const long n8 = n >> 3;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {

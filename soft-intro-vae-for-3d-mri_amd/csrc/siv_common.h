@@ -177,6 +177,13 @@ struct PhiloxMask {
     int on;
 };
 
+// fp32 -> bf16 bits with round-to-nearest-even (NaN stays NaN)
+__device__ __forceinline__ uint32_t bf16_rne(float f) {
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;        // quiet NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
 __device__ __forceinline__ float leaky(float z, float slope) { return z > 0.f ? z : z * slope; }
 __device__ __forceinline__ float leaky_grad(float z, float slope) { return z > 0.f ? 1.f : slope; }
 

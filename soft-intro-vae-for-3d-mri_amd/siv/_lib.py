@@ -56,6 +56,10 @@ SIGNATURES = {
     "siv_bn_act_fwd_grouped": [_f, _f, _f, _f, _f, _f, _f, _fl, _fl, _i, _fl, _f, _i, _i, _i, _i, _i, _i, _f],
     "siv_bn_act_bwd_grouped": [_f, _f, _f, _f, _f, _f, _f, _f, _fl, _fl, _i, _fl, _f, _f, _f, _f, _i,
                                _i, _i, _i, _i, _i, _i, _f, _sz, _f],
+    "siv_bn_act_bf16_supported": [_i],
+    "siv_bn_act_fwd_bf16": [_f, _f, _f, _f, _f, _f, _f, _fl, _fl, _i, _fl, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f],
+    "siv_bn_act_bwd_bf16": [_f, _f, _f, _f, _f, _f, _f, _f, _fl, _fl, _i, _fl, _f, _f, _f, _f, _i,
+                            _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_act_dropout_fwd": [_f, _f, _fl, _fl, _f, _l, _f],
     "siv_act_dropout_bwd": [_f, _f, _f, _fl, _fl, _f, _l, _f],
     "siv_reparam_fwd": [_f, _f, _f, _fl, _f, _l, _f],

@@ -57,6 +57,23 @@ class _Packed:
         self.h = h
 
 
+_depth = 0      # > 0 inside an encoder / decoder forward pass (``scoped``)
+
+
+def native() -> bool:
+    """True where operators that can write the bf16 copy of what they keep THEMSELVES should do so: bf16
+    storage is on, an encoder / decoder pass is running and autograd is recording.  (BatchNorm + activation
+    emits the copies of its input and output in its own pass and reads the bf16 input in its backward pass;
+    everything else goes through the saved-tensor hooks below.)"""
+    return _storage == "bf16" and _depth > 0 and torch.is_grad_enabled()
+
+
+def count_native(*tensors) -> None:
+    for t in tensors:
+        packed["tensors"] += 1
+        packed["bytes_fp32"] += 4 * t.numel()
+
+
 def _eligible(t) -> bool:
     if not torch.is_tensor(t) or t.dtype != torch.float32 or t.numel() < MIN_NUMEL:
         return False
@@ -84,8 +101,13 @@ def scoped(forward):
     """Decorator for an encoder / decoder ``forward``: tensors saved inside follow the storage mode."""
     @functools.wraps(forward)
     def wrapper(*args, **kwargs):
+        global _depth
         if _storage == "fp32" or not torch.is_grad_enabled():
             return forward(*args, **kwargs)
-        with torch.autograd.graph.saved_tensors_hooks(_pack, _unpack):
-            return forward(*args, **kwargs)
+        _depth += 1
+        try:
+            with torch.autograd.graph.saved_tensors_hooks(_pack, _unpack):
+                return forward(*args, **kwargs)
+        finally:
+            _depth -= 1
     return wrapper

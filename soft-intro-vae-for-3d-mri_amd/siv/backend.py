@@ -533,10 +533,16 @@ class HipBackend:
     def _groups_of(mean) -> int:
         return 1 if mean.dim() == 1 else int(mean.shape[0])
 
-    def bn_act_fwd(self, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps, out=None):
+    def bn_bf16_supported(self, y) -> bool:
+        """Can ``bn_act_fwd(..., emit_bf16=True)`` / a bf16 ``y`` in ``bn_act_bwd`` be used for this tensor?"""
+        return bool(y.is_cuda and y.dim() == 5 and self.lib.siv_bn_act_bf16_supported(int(y.shape[1]))
+                    and y.shape[0] * y.shape[2] * y.shape[3] * y.shape[4] < (1 << 31))
+
+    def bn_act_fwd(self, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps, out=None, emit_bf16=False):
         """``mean`` / ``var`` of shape (groups, C) select the grouped operator (one set of statistics per
         consecutive part of the batch).  ``out``: write the result there (a dense channels-last tensor of the
-        output shape, e.g. a batch slice of a larger buffer) instead of into a new tensor."""
+        output shape, e.g. a batch slice of a larger buffer) instead of into a new tensor.  ``emit_bf16``:
+        returns (out, bf16 copy of y, bf16 copy of out), both copies written by the same pass."""
         self._check_dev(y, mean, var, gamma, beta, res, keep)
         groups = self._groups_of(mean)
         mean, var = mean.contiguous(), var.contiguous()
@@ -552,6 +558,14 @@ class HipBackend:
         if keep is not None:
             keep = cl(keep)
             assert keep.dtype == torch.uint8 and keep.shape == out.shape
+        if emit_bf16:
+            yh = torch.empty_like(y, dtype=torch.bfloat16)
+            oh = torch.empty_like(out, dtype=torch.bfloat16)
+            _lib.check(self.lib.siv_bn_act_fwd_bf16(_p(y), _p(mean), _p(var), _p(gamma), _p(beta), _p(res), _p(keep),
+                                                    float(p), float(slope), int(pool), float(eps), _p(out), _p(yh),
+                                                    _p(oh), N, D, H, W, C, groups, self._stream(y)),
+                       "siv_bn_act_fwd_bf16")
+            return out, yh, oh
         _lib.check(self.lib.siv_bn_act_fwd_grouped(_p(y), _p(mean), _p(var), _p(gamma), _p(beta), _p(res), _p(keep),
                                                    float(p), float(slope), int(pool), float(eps), _p(out),
                                                    N, D, H, W, C, groups, self._stream(y)), "siv_bn_act_fwd")
@@ -560,14 +574,15 @@ class HipBackend:
     def bn_act_bwd(self, dout, y, mean, var, gamma, beta, res, keep, p, slope, pool, eps,
                    want_affine: bool, want_res: bool, dgamma_out=None, dbeta_out=None):
         """With ``dgamma_out`` / ``dbeta_out`` the affine gradients are ADDED into those buffers."""
-        self._check_dev(dout, y, mean, var, gamma, beta, res, keep, dgamma_out, dbeta_out)
+        y_bf16 = y.dtype == torch.bfloat16              # the bf16 copy bn_act_fwd(emit_bf16=True) made
+        self._check_dev(dout, None if y_bf16 else y, mean, var, gamma, beta, res, keep, dgamma_out, dbeta_out)
         groups = self._groups_of(mean)
         mean, var = mean.contiguous(), var.contiguous()
         dout, y = cl(dout), cl(y)
         res = cl(res) if res is not None else None
         keep = cl(keep) if keep is not None else None
         N, C, D, H, W = y.shape
-        dy = like(y)
+        dy = empty_cl(tuple(y.shape), dout)
         acc = 0
         if want_affine and dgamma_out is not None:
             assert dbeta_out is not None and dgamma_out.is_contiguous() and dbeta_out.is_contiguous()
@@ -575,12 +590,13 @@ class HipBackend:
         else:
             dgamma = torch.empty(C, device=y.device, dtype=torch.float32) if want_affine else None
             dbeta = torch.empty(C, device=y.device, dtype=torch.float32) if want_affine else None
-        dres = like(y) if (want_res and res is not None) else None
+        dres = empty_cl(tuple(y.shape), dout) if (want_res and res is not None) else None
         ws, wsb = self._workspace(y)
-        _lib.check(self.lib.siv_bn_act_bwd_grouped(_p(dout), _p(y), _p(mean), _p(var), _p(gamma), _p(beta), _p(res),
-                                                   _p(keep), float(p), float(slope), int(pool), float(eps),
-                                                   _p(dy), _p(dgamma), _p(dbeta), _p(dres), acc, N, D, H, W, C,
-                                                   groups, ws, wsb, self._stream(y)), "siv_bn_act_bwd")
+        fn = self.lib.siv_bn_act_bwd_bf16 if y_bf16 else self.lib.siv_bn_act_bwd_grouped
+        _lib.check(fn(_p(dout), _p(y), _p(mean), _p(var), _p(gamma), _p(beta), _p(res),
+                      _p(keep), float(p), float(slope), int(pool), float(eps),
+                      _p(dy), _p(dgamma), _p(dbeta), _p(dres), acc, N, D, H, W, C,
+                      groups, ws, wsb, self._stream(y)), "siv_bn_act_bwd")
         return dy, dgamma, dbeta, dres
 
     def act_dropout_fwd(self, x, keep, p, slope):

@@ -10,6 +10,7 @@ from typing import Optional
 import torch
 from torch.autograd import Function
 
+from . import activations
 from .backend import get_backend
 
 BN_EPS = 1e-5
@@ -80,7 +81,10 @@ def _wgrad_on_side_stream(B, x, dy, ready, wgrad_fn):
 class _Conv3dK3(Function):
     @staticmethod
     def forward(ctx, x, w, bias, ups, bn=None):
-        ctx.save_for_backward(x, w)
+        # bf16 activation storage: the operator that produced x may have written its bf16 copy in the same
+        # pass -- that copy is what the weight gradient gets (expanded only if a weight gradient is asked for)
+        xh = getattr(x, "_siv_bf16", None) if activations.get_storage() == "bf16" else None
+        ctx.save_for_backward(x if xh is None else xh, w)
         ctx.ups = ups
         ctx.has_bias = bias is not None
         ctx.set_materialize_grads(False)       # no zero tensors for the unused (mean, var) outputs
@@ -107,6 +111,8 @@ class _Conv3dK3(Function):
         ready = _side_ready(B, dy) if direct else None
         if ctx.needs_input_grad[0]:
             dx = B.conv3d_k3_dgrad(dy, w, ctx.ups)
+        if want_w and x.dtype == torch.bfloat16:
+            x = B.from_bf16(x)
         if direct:
             _wgrad_on_side_stream(B, x, dy, ready,
                                   lambda: B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b, ctx.w_buf, ctx.b_buf))
@@ -233,7 +239,8 @@ def add_act(a, b, slope: float):
 
 class _BnAct(Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, res, keep, bn, p, slope, pool, train, stats=None, groups=1, out=None):
+    def forward(ctx, y, gamma, beta, res, keep, bn, p, slope, pool, train, stats=None, groups=1, out=None,
+                emit_bf16=False):
         B = get_backend()
         if train and stats is not None:
             mean, var = stats          # already computed (and the running statistics updated)
@@ -248,16 +255,26 @@ class _BnAct(Function):
         else:
             mean, var = bn.running_mean, bn.running_var
         # `out` (an Into holder): the result is written into that tensor, e.g. a batch slice of a larger buffer
-        out = B.bn_act_fwd(y, mean, var, gamma, beta, res, keep, p, slope, pool, bn.eps,
-                           **({"out": out.t} if out is not None else {}))
+        dst = {"out": out.t} if out is not None else {}
+        oh = None
+        if emit_bf16:
+            # bf16 activation storage: this pass also writes the bf16 copies of y (kept for backward in place
+            # of y) and of the output (kept by the convolution that consumes it, for its weight gradient)
+            out, yh, oh = B.bn_act_fwd(y, mean, var, gamma, beta, res, keep, p, slope, pool, bn.eps, emit_bf16=True,
+                                       **dst)
+            activations.count_native(y, out)
+            y = yh
+            ctx.mark_non_differentiable(oh)
+        else:
+            out = B.bn_act_fwd(y, mean, var, gamma, beta, res, keep, p, slope, pool, bn.eps, **dst)
         ctx.save_for_backward(y, mean, var, gamma, beta, res, keep)
         ctx.cfg = (p, slope, pool, bn.eps, train)
         ctx.g_buf, ctx.b_buf = _grad_buf(gamma), _grad_buf(beta)
-        return out
+        return out, oh
 
     @staticmethod
-    def backward(ctx, dout):
-        y, mean, var, gamma, beta, res, keep = ctx.saved_tensors
+    def backward(ctx, dout, d_oh=None):
+        y, mean, var, gamma, beta, res, keep = ctx.saved_tensors        # y: fp32, or its bf16 copy
         p, slope, pool, eps, train = ctx.cfg
         if not train:
             raise NotImplementedError("backward through evaluation-mode BatchNorm is not part of the "
@@ -274,7 +291,7 @@ class _BnAct(Function):
         if not ctx.needs_input_grad[0]:
             dy = None
         return (dy, dg if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None,
-                dres, None, None, None, None, None, None, None, None, None)
+                dres, None, None, None, None, None, None, None, None, None, None)
 
 
 class Into:
@@ -359,8 +376,13 @@ def bn_act(y, bn, slope: float, pool: int = 1, residual=None, keep=None, p: floa
     updates the running statistics once, in order."""
     if pool not in (1, 2):
         raise ValueError(f"only stride/pool 1 or 2 is supported (got {pool})")
-    return _BnAct.apply(y, bn.weight, bn.bias, residual, keep, bn, p, slope, pool, train, stats,
-                        groups if train else 1, Into(out) if out is not None else None)
+    emit = (train and activations.native() and y.dtype == torch.float32 and y.numel() >= activations.MIN_NUMEL
+            and hasattr(get_backend(), "bn_bf16_supported") and get_backend().bn_bf16_supported(y))
+    o, oh = _BnAct.apply(y, bn.weight, bn.bias, residual, keep, bn, p, slope, pool, train, stats,
+                         groups if train else 1, Into(out) if out is not None else None, emit)
+    if oh is not None:
+        o._siv_bf16 = oh          # found by the convolution that takes `o` as its input
+    return o
 
 
 def conv_bn_act(x, conv, bn, slope: float, ups: int = 1, pool: int = 1, residual=None, keep=None,

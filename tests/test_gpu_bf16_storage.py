@@ -145,3 +145,43 @@ def test_bf16_storage_step():
     assert peak16 < 0.8 * peak32, (peak16, peak32)
     print(f"bf16 storage: {n_packed} tensors packed, worst gradient error {worst:.2e} of max "
           f"(fp32 mode {worst32:.2e}), peak memory {peak16 / 2**20:.0f} MiB against {peak32 / 2**20:.0f} MiB")
+
+
+@pytest.mark.parametrize("c,dims,n,groups,pool,use_res,p", [
+    (64, (8, 12, 8), 2, 1, 1, False, 0.25), (64, (8, 12, 8), 2, 1, 2, False, 0.0), (256, (10, 12, 10), 4, 2, 1, True, 0.0),
+    (128, (20, 24, 20), 2, 2, 2, False, 0.0), (8, (4, 6, 4), 2, 1, 1, True, 0.35),
+])
+def test_bn_act_bf16_entry_points(c, dims, n, groups, pool, use_res, p):
+    """siv_bn_act_fwd_bf16 / siv_bn_act_bwd_bf16: the forward pass that also writes the bf16 copies of its input
+    and output (bit-identical to torch's rounding, output unchanged), and the backward pass that reads the
+    convolution output from its bf16 copy (bit-identical to the fp32-reading kernels fed the expanded copy)."""
+    import siv.backend as sb
+    B = sb.get_backend()
+    gen = torch.Generator().manual_seed(c + pool + groups)
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last_3d)
+    y = cl(torch.randn(n, c, *dims, generator=gen) * 2 + 0.5)
+    gamma, beta = (1 + 0.3 * torch.randn(c, generator=gen)).cuda(), (0.2 * torch.randn(c, generator=gen)).cuda()
+    res = cl(torch.randn(n, c, *dims, generator=gen)) if use_res else None
+    odims = tuple(d // pool for d in dims)
+    keep = cl((torch.rand(n, c, *odims, generator=gen) >= p).to(torch.uint8)) if p > 0 else None
+    dout = cl(torch.randn(n, c, *odims, generator=gen))
+    assert B.bn_bf16_supported(y)
+    mean, var = B.bn_stats(y, None, None, None, 0.1, groups)
+    out = B.bn_act_fwd(y, mean, var, gamma, beta, res, keep, p, 0.2, pool, 1e-5)
+    out2, yh, oh = B.bn_act_fwd(y, mean, var, gamma, beta, res, keep, p, 0.2, pool, 1e-5, emit_bf16=True)
+    assert torch.equal(out, out2)
+    assert yh.dtype == torch.bfloat16 and torch.equal(yh, y.to(torch.bfloat16)) and yh.stride() == y.stride()
+    assert torch.equal(oh, out.to(torch.bfloat16))
+    dy, dg, db, dres = B.bn_act_bwd(dout, yh, mean, var, gamma, beta, res, keep, p, 0.2, pool, 1e-5, True, use_res)
+    dy1, dg1, db1, dres1 = B.bn_act_bwd(dout, yh.float(), mean, var, gamma, beta, res, keep, p, 0.2, pool, 1e-5, True,
+                                        use_res)
+    assert torch.equal(dy, dy1) and torch.equal(dg, dg1) and torch.equal(db, db1)
+    if use_res:
+        assert torch.equal(dres, dres1)
+    assert not B.bn_bf16_supported(torch.zeros(1, 6, 2, 2, 2, device="cuda"))
+    import siv._lib as L
+    y6 = torch.zeros(2, 6, 2, 2, 2, device="cuda").contiguous(memory_format=torch.channels_last_3d)
+    m6, v6 = B.bn_stats(y6, None, None, None, 0.1)
+    g6 = torch.ones(6, device="cuda")
+    with pytest.raises(L.SivError):                        # no float4 kernel for 6 channels: no bf16 copies
+        B.bn_act_fwd(y6, m6, v6, g6, g6, None, None, 0.0, 0.2, 1, 1e-5, emit_bf16=True)
