@@ -333,6 +333,32 @@ int siv_bn_act_fwd_bf16(const float* y, const float* mean, const float* var,
                         const uint8_t* keep, float p, float slope, int pool, float eps,
                         float* out, void* y_bf16, void* out_bf16, int N, int D, int H, int W, int C,
                         int groups, siv_stream_t stream);
+/* The same for the two fused ends of the model.  siv_conv1_bnact_fwd_bf16 = siv_conv1_bnact_fwd that also writes
+ * the bf16 copy of its output (out_bf16, NULL = none), which the first wide convolution keeps for its weight
+ * gradient.  siv_bnact_conv3d_k3_to1_fwd_bf16 = siv_bnact_conv3d_k3_to1_fwd that also writes the bf16 copy of x, the
+ * raw tensor it normalises (x_bf16, NULL = none; every voxel is written once, by the block that owns it);
+ * ..._dgrad_bf16 / ..._wgrad_bf16 read x from that copy. */
+int siv_conv1_bnact_fwd_bf16(const float* x, const float* w, const float* bias, const float* gamma,
+                             const float* beta, const uint8_t* keep, uint64_t mask_seed,
+                             uint64_t mask_stream_id, const uint64_t* mask_epoch, float p, float slope,
+                             float eps, int train, float* mean, float* var, float* running_mean,
+                             float* running_var, int64_t* num_batches_tracked, float momentum,
+                             float* out, void* out_bf16, int N, int D, int H, int W, int Cout, void* ws,
+                             size_t ws_bytes, siv_stream_t stream);
+int siv_bnact_conv3d_k3_to1_fwd_bf16(const float* x, const float* mean, const float* var,
+                                     const float* gamma, const float* beta, float eps, float slope,
+                                     const float* w, const float* bias, float* y, void* x_bf16, int N,
+                                     int D, int H, int W, int Cin, siv_stream_t stream);
+int siv_bnact_conv3d_k3_to1_dgrad_bf16(const float* dy, const float* w, const void* x_bf16,
+                                       const float* mean, const float* var, const float* gamma,
+                                       const float* beta, float eps, float slope, float* dx,
+                                       float* dgamma, float* dbeta, int accumulate, int N, int D, int H,
+                                       int W, int Cin, void* ws, size_t ws_bytes, siv_stream_t stream);
+int siv_bnact_conv3d_k3_to1_wgrad_bf16(const void* x_bf16, const float* mean, const float* var,
+                                       const float* gamma, const float* beta, float eps, float slope,
+                                       const float* dy, float* dw, float* dbias, int N, int D, int H,
+                                       int W, int Cin, int accumulate, void* ws, size_t ws_bytes,
+                                       siv_stream_t stream);
 int siv_bn_act_bwd_bf16(const float* dout, const void* y_bf16, const float* mean, const float* var,
                         const float* gamma, const float* beta, const float* residual,
                         const uint8_t* keep, float p, float slope, int pool, float eps,

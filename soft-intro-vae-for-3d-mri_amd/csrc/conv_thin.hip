@@ -135,6 +135,23 @@ __global__ __launch_bounds__(256) void one_to_c_k(const float* __restrict__ a,
 // ---------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Four consecutive channels of a voxel held as bf16 (8 bytes): the storage format of activations that are
+// kept for the backward pass when bf16 activation storage is on.  `e` is the ELEMENT index of the first channel.
+__device__ __forceinline__ void thin_st_bf4(uint16_t* __restrict__ p, long e, float4 v) {
+    *reinterpret_cast<uint2*>(p + e) = make_uint2(bf16_rne(v.x) | (bf16_rne(v.y) << 16), bf16_rne(v.z) | (bf16_rne(v.w) << 16));
+}
+// a float4 of four channels from an fp32 tensor, or (BF) from its bf16 copy
+template <bool BF>
+__device__ __forceinline__ float4 thin_ld4(const float* __restrict__ p, long e) {
+    if constexpr (BF) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p) + e);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u));
+    } else {
+        return *reinterpret_cast<const float4*>(p + e);
+    }
+}
+
 __global__ __launch_bounds__(256, 3) void one_to_c_mfma_k(const float* __restrict__ a,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ bias,
@@ -243,7 +260,8 @@ __global__ __launch_bounds__(256, 3) void one_to_c_mfma_k(const float* __restric
 //   STAGE 1: dy = a * (dz - sum(dz)/M - xhat * sum(dz*xhat)/M)                     (sums[2][C] finalised)
 // Layout and tiling as one_to_c_mfma_k: a lane holds channels 4q .. 4q+3 of voxels 4 kk + e.
 // ---------------------------------------------------------------------------------
-template <int STAGE>
+// YBF: y points at the bf16 copy of the BatchNorm input.
+template <int STAGE, bool YBF>
 __global__ __launch_bounds__(256, 3) void tail_bn_bwd_k(const float* __restrict__ g1,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ y, BnPrologue bn,
@@ -303,7 +321,7 @@ __global__ __launch_bounds__(256, 3) void tail_bn_bwd_k(const float* __restrict_
                 const int m = 4 * kk + e;
                 const int dyy = 2 * tl + (m >> 3), dx = m & 7;
                 ok[e] = qok && y0 + dyy < H && x0 + dx < W;
-                yv[e] = *reinterpret_cast<const float4*>(ok[e] ? y + base + ((long)dyy * W + dx) * C : y);
+                yv[e] = thin_ld4<YBF>(y, ok[e] ? base + ((long)dyy * W + dx) * C : 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             const float* hp = hal[buf] + (wv * TH_H + 2 * tl + (q >> 3)) * TH_W + (q & 7);
@@ -393,7 +411,9 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                                                     const float* __restrict__ sums, float invM,
                                                     float* __restrict__ part, float* __restrict__ out,
                                                     int N, int D, int H, int W, int C, int nbd, int nbh,
-                                                    int nbw, int bricks_per_block, int nbricks) {
+                                                    int nbw, int bricks_per_block, int nbricks,
+                                                    uint16_t* __restrict__ out_bf16) {
+    // out_bf16 (SM_APPLY, optional): a bf16 copy of the output, written beside it
     __shared__ float hal[2][TH_V];
     // dropout: a mask tensor (keep), or the mask drawn here from the element index (rk.on), or none
     const bool masked = MODE != SM_STATS && (keep != nullptr || rk.on);
@@ -515,8 +535,10 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                         o[j] = ca[j] * (dz - k1[j] - xh * k2[j]);
                     }
                 }
-                if ((MODE == SM_APPLY || MODE == SM_BAPP) && ok[e])
+                if ((MODE == SM_APPLY || MODE == SM_BAPP) && ok[e]) {
                     *reinterpret_cast<float4*>(out + off[e]) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (MODE == SM_APPLY && out_bf16) thin_st_bf4(out_bf16, off[e], make_float4(o[0], o[1], o[2], o[3]));
+                }
             }
         }
     }
@@ -866,13 +888,15 @@ __device__ __forceinline__ float bn_act1(float x, float a, float b, float slope)
 // BN: the operand a is the raw output of the convolution in front; BatchNorm + LeakyReLU are applied to
 // every loaded value (coefficients in LDS), out-of-volume voxels stay zero (the padding of the ACTIVATED
 // tensor).  The activated tensor is then never written or read.
+// a_bf16 (optional): a bf16 copy of the operand, written by the block that owns a voxel (the interior of its
+// column, its own z range) from the very values it loaded.
 template <int KG, bool BN>
 __global__ __launch_bounds__(256, 2) void c_to_one_zwalk12_k(const float* __restrict__ a,
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ bias,
                                                              float* __restrict__ out, int N, int D, int H,
                                                              int W, int flip, int nth, int ntw, int zsplit,
-                                                             BnPrologue bn) {
+                                                             BnPrologue bn, uint16_t* __restrict__ a_bf16) {
     constexpr int C = 8 * KG;
     static_assert(ZX_TILES == 8, "two row tiles per wave");
     __shared__ float pim[2][ZX_TILES * 32 * C1_PP];    // all 256 rows of the eight tiles are written
@@ -907,15 +931,17 @@ __global__ __launch_bounds__(256, 2) void c_to_one_zwalk12_k(const float* __rest
     const int y0 = ty * ZX_H, x0 = tx * ZX_W;
 
     int off[2];
-    bool okv[2];
+    bool okv[2], own[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int u = (wv + 4 * q) * 32 + i;
         const int hy = u / ZX_HW, hx = u % ZX_HW;
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
         okv[q] = u < ZX_HV && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        own[q] = okv[q] && hy >= 1 && hy <= ZX_H && hx >= 1 && hx <= ZX_W;     // not a halo voxel of this column
         off[q] = okv[q] ? (gy * W + gx) * C + 4 * h : 0;
     }
+    uint16_t* an16 = a_bf16 ? a_bf16 + (long)n * D * H * W * C : nullptr;
     const float* an = a + (long)n * D * H * W * C;
     float4 av[2][2][KG];
     auto load_plane = [&](float4 (&dst)[2][KG], int z) {
@@ -952,6 +978,14 @@ __global__ __launch_bounds__(256, 2) void c_to_one_zwalk12_k(const float* __rest
                 for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
             const bool zin = z >= 0 && z < D;
             const bool ok0 = zin && okv[0], ok1 = zin && okv[1];
+            if (an16 && z >= zlo && z < zhi) {         // the raw values of the voxels this block owns, as bf16
+                uint16_t* pl16 = an16 + (long)z * H * W * C;
+#pragma unroll
+                for (int g = 0; g < KG; ++g) {
+                    if (own[0]) thin_st_bf4(pl16, off[0] + 8 * g, av[par][0][g]);
+                    if (own[1]) thin_st_bf4(pl16, off[1] + 8 * g, av[par][1][g]);
+                }
+            }
 #pragma unroll
             for (int g = 0; g < KG; ++g) {              // the two row tiles alternate: independent chains
                 float4 v0 = av[par][0][g], v1 = av[par][1][g];
@@ -1074,7 +1108,8 @@ __global__ __launch_bounds__(256) void thin_wg_k(const float* __restrict__ a,
 // eight 32-cycle matrix instructions.  The four waves are combined through LDS in fixed order and
 // one partial row per block is written, part[block][C][28], as above.
 // ---------------------------------------------------------------------------------
-template <bool BN>
+// GBF: g points at the bf16 copy of the (raw) multi-channel operand.
+template <bool BN, bool GBF>
 __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict__ a,
                                                       const float* __restrict__ g,
                                                       float* __restrict__ part, int N, int D, int H, int W,
@@ -1125,7 +1160,7 @@ __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict
         __builtin_amdgcn_sched_barrier(0);
         const int gz = z0 + wv;
         if (gz >= D) continue;
-        const float* gp = g + ((((long)n * D + gz) * H + y0) * W + x0) * C + 4 * q;
+        const long gbase = ((((long)n * D + gz) * H + y0) * W + x0) * C + 4 * q;
         const float* hp = hal[buf] + wv * TH_H * TH_W + kk;
         // group u (0..15): brick row u >> 1, voxels 4 (u & 1) + kk
         auto load4 = [&](float4 (&dst)[4], int c4) {
@@ -1135,7 +1170,7 @@ __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict
                 const bool ok = qok && y0 + dy < H && x0 + dx < W;
                 // masked lanes read the start of the tensor (no branch around the load) and are
                 // zeroed where the value is used, so nothing waits for the load here
-                dst[u] = *reinterpret_cast<const float4*>(ok ? gp + (dy * W + dx) * C : g);
+                dst[u] = thin_ld4<GBF>(g, ok ? gbase + (long)(dy * W + dx) * C : 0);
             }
         };
         float4 av[2][4];
@@ -1285,14 +1320,14 @@ bool k3_thin_bn_fwd_supported(int N, int D, int H, int W, int Cin) {
     return zx_plan(N, D, H, W, Cin, zx);
 }
 int k3_thin_bn_fwd_launch(const float* x, const BnPrologue& bn, const float* w, const float* bias, float* out,
-                          int N, int D, int H, int W, int Cin, hipStream_t s) {
+                          int N, int D, int H, int W, int Cin, hipStream_t s, void* x_bf16) {
     ZxPlan zx;
     if (!zx_plan(N, D, H, W, Cin, zx)) {
         set_error("bnact_conv3d_k3_to1: unsupported shape (needs 64 channels, D >= 16, H >= 12, W >= 16)");
         return SIV_EINVAL;
     }
     c_to_one_zwalk12_k<8, true><<<(unsigned)zx.nb, 256, 0, s>>>(x, w, bias, out, N, D, H, W, 0, zx.nth, zx.ntw,
-                                                               zx.zsplit, bn);
+                                                               zx.zsplit, bn, (uint16_t*)x_bf16);
     SIV_CHECK_LAUNCH("bnact_conv3d_k3_to1(fwd)");
     return SIV_OK;
 }
@@ -1304,7 +1339,7 @@ int bn_bwd_finalize_launch(const float* part, int nblk, int C, float* sums, floa
 // from the convolution's output gradient g1[N][D][H][W]
 int k3_thin_bn_dgrad_launch(const float* g1, const float* w, const float* x, const BnPrologue& bn, float* dx,
                             float* dgamma, float* dbeta, int accumulate, int N, int D, int H, int W, int Cin,
-                            void* ws, size_t ws_bytes, hipStream_t s) {
+                            void* ws, size_t ws_bytes, hipStream_t s, bool x_bf16) {
     if (Cin % 4 != 0 || Cin > 64) {
         set_error("bnact_conv3d_k3_to1(dgrad): needs Cin %% 4 == 0 and Cin <= 64 (got %d)", Cin);
         return SIV_EINVAL;
@@ -1323,13 +1358,21 @@ int k3_thin_bn_dgrad_launch(const float* g1, const float* w, const float* x, con
     float* part = (float*)ws;
     float* sums = (float*)((char*)ws + part_bytes);
     const float invM = 1.0f / (float)((long)N * D * H * W);
-    tail_bn_bwd_k<0><<<(unsigned)nblk, 256, 0, s>>>(g1, w, x, bn, nullptr, invM, part, nullptr, N, D, H, W, Cin, nbd,
-                                                   nbh, nbw, bpb, (int)nbricks);
+    if (x_bf16)
+        tail_bn_bwd_k<0, true><<<(unsigned)nblk, 256, 0, s>>>(g1, w, x, bn, nullptr, invM, part, nullptr, N, D, H, W, Cin,
+                                                             nbd, nbh, nbw, bpb, (int)nbricks);
+    else
+        tail_bn_bwd_k<0, false><<<(unsigned)nblk, 256, 0, s>>>(g1, w, x, bn, nullptr, invM, part, nullptr, N, D, H, W, Cin,
+                                                              nbd, nbh, nbw, bpb, (int)nbricks);
     SIV_CHECK_LAUNCH("bnact_conv3d_k3_to1(dgrad, sums)");
     const int rc = bn_bwd_finalize_launch(part, (int)nblk, Cin, sums, dgamma, dbeta, accumulate, s);
     if (rc) return rc;
-    tail_bn_bwd_k<1><<<(unsigned)nblk, 256, 0, s>>>(g1, w, x, bn, sums, invM, nullptr, dx, N, D, H, W, Cin, nbd, nbh,
-                                                   nbw, bpb, (int)nbricks);
+    if (x_bf16)
+        tail_bn_bwd_k<1, true><<<(unsigned)nblk, 256, 0, s>>>(g1, w, x, bn, sums, invM, nullptr, dx, N, D, H, W, Cin, nbd,
+                                                             nbh, nbw, bpb, (int)nbricks);
+    else
+        tail_bn_bwd_k<1, false><<<(unsigned)nblk, 256, 0, s>>>(g1, w, x, bn, sums, invM, nullptr, dx, N, D, H, W, Cin, nbd,
+                                                              nbh, nbw, bpb, (int)nbricks);
     SIV_CHECK_LAUNCH("bnact_conv3d_k3_to1(dgrad, apply)");
     return SIV_OK;
 }
@@ -1366,7 +1409,7 @@ int stem_bnact_fwd_launch(const float* x, const float* w, const float* bias, con
                           const uint8_t* keep, const PhiloxMask& rk, float p, float slope, float eps, int train,
                           float* mean, float* var, float* running_mean, float* running_var, int64_t* nbt,
                           float momentum, float* out, int N, int D, int H, int W, int C, void* ws, size_t ws_bytes,
-                          hipStream_t s) {
+                          hipStream_t s, void* out_bf16) {
     StemGrid g;
     int rc = stem_grid("conv1_bnact_fwd", N, D, H, W, C, ws_bytes, g);
     if (rc) return rc;
@@ -1375,14 +1418,15 @@ int stem_bnact_fwd_launch(const float* x, const float* w, const float* bias, con
         float* part = (float*)ws;
         stem_bn_k<SM_STATS><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, nullptr, PhiloxMask{}, 0.f, nullptr, nullptr, 0.f, part,
                                                             nullptr, N, D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb,
-                                                            (int)g.nbricks);
+                                                            (int)g.nbricks, nullptr);
         SIV_CHECK_LAUNCH("conv1_bnact_fwd(statistics)");
         rc = bn_finalize_launch(bias, part, (int)g.nblk, (long)N * D * H * W, C, mean, var, running_mean, running_var,
                                 nbt, momentum, s);
         if (rc) return rc;
     }
     stem_bn_k<SM_APPLY><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, nullptr, nullptr, 0.f, nullptr, out, N,
-                                                        D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks);
+                                                        D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks,
+                                                        (uint16_t*)out_bf16);
     SIV_CHECK_LAUNCH("conv1_bnact_fwd(apply)");
     return SIV_OK;
 }
@@ -1401,12 +1445,12 @@ int stem_bnact_bwd_launch(const float* dout, const float* x, const float* w, con
     float* sums = (float*)((char*)ws + g.part_bytes);
     const float invM = 1.0f / (float)((long)N * D * H * W);
     stem_bn_k<SM_BSUM><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, dout, nullptr, invM, part, nullptr, N, D,
-                                                       H, W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks);
+                                                       H, W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks, nullptr);
     SIV_CHECK_LAUNCH("conv1_bnact_bwd(sums)");
     rc = bn_bwd_finalize_launch(part, (int)g.nblk, C, sums, dgamma, dbeta, accumulate, s);
     if (rc) return rc;
     stem_bn_k<SM_BAPP><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, dout, sums, invM, nullptr, dy, N, D, H,
-                                                       W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks);
+                                                       W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks, nullptr);
     SIV_CHECK_LAUNCH("conv1_bnact_bwd(apply)");
     return SIV_OK;
 }
@@ -1449,7 +1493,7 @@ int k3_thin_fwd_launch(const float* a, const float* w, const float* bias, float*
     ZxPlan zx;
     if (zx_plan(N, D, H, W, Ca, zx)) {
         c_to_one_zwalk12_k<8, false><<<(unsigned)zx.nb, 256, 0, s>>>(a, w, bias, out, N, D, H, W, flip, zx.nth,
-                                                                    zx.ntw, zx.zsplit, BnPrologue{});
+                                                                    zx.ntw, zx.zsplit, BnPrologue{}, nullptr);
         SIV_CHECK_LAUNCH("conv3d_k3(thin, z-walk 12x16)");
         return SIV_OK;
     }
@@ -1483,7 +1527,7 @@ int k3_thin_fwd_launch(const float* a, const float* w, const float* bias, float*
 
 int k3_thin_wgrad_launch(const float* x, const float* dy, float* dw, float* dbias, int N, int D, int H,
                          int W, int Cin, int Cout, int accumulate, void* ws, size_t ws_bytes,
-                         hipStream_t s, const BnPrologue* bn) {
+                         hipStream_t s, const BnPrologue* bn, bool x_bf16) {
     const int nbd = (D + TB_D - 1) / TB_D, nbh = (H + TB_H - 1) / TB_H, nbw = (W + TB_W - 1) / TB_W;
     const long nbricks = (long)N * nbd * nbh * nbw;
     const int mode = (Cin == 1) ? 0 : 1;
@@ -1506,11 +1550,17 @@ int k3_thin_wgrad_launch(const float* x, const float* dy, float* dw, float* dbia
         set_error("bnact_conv3d_k3_to1(wgrad): needs at most 64 input channels");
         return SIV_EINVAL;
     }
-    if (mfma && bn)
-        thin_wg_mfma_k<true><<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb, *bn);
+    if (x_bf16 && !(mfma && bn)) {
+        set_error("conv3d_k3_wgrad(thin): a bf16 operand is read only by the BatchNorm-prologue form");
+        return SIV_EINVAL;
+    }
+    if (mfma && bn && x_bf16)
+        thin_wg_mfma_k<true, true><<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb, *bn);
+    else if (mfma && bn)
+        thin_wg_mfma_k<true, false><<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb, *bn);
     else if (mfma)
-        thin_wg_mfma_k<false><<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb,
-                                                            BnPrologue{});
+        thin_wg_mfma_k<false, false><<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb,
+                                                                   BnPrologue{});
     else
         thin_wg_k<<<(unsigned)nblk, 256, 0, s>>>(a, g, part, N, D, H, W, C, nbd, nbh, nbw, bpb);
     SIV_CHECK_LAUNCH("conv3d_k3_wgrad(thin)");

@@ -165,15 +165,15 @@ long k3_thin_fwd_stat_blocks(int N, int D, int H, int W, int Ca, int Cb);
 int k3_thin_fwd_launch(const float*, const float*, const float*, float*, int, int, int, int, int, int,
                        int flip, hipStream_t, float* stat_part);
 int k3_thin_wgrad_launch(const float*, const float*, float*, float*, int, int, int, int, int, int,
-                         int, void*, size_t, hipStream_t, const BnPrologue* bn);
+                         int, void*, size_t, hipStream_t, const BnPrologue* bn, bool x_bf16 = false);
 int k3_thin_bn_dgrad_launch(const float* g1, const float* w, const float* x, const BnPrologue& bn, float* dx,
                             float* dgamma, float* dbeta, int accumulate, int N, int D, int H, int W, int Cin,
-                            void* ws, size_t ws_bytes, hipStream_t s);
+                            void* ws, size_t ws_bytes, hipStream_t s, bool x_bf16 = false);
 int stem_bnact_fwd_launch(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
                           const uint8_t* keep, const PhiloxMask& rk, float p, float slope, float eps, int train,
                           float* mean, float* var, float* running_mean, float* running_var, int64_t* nbt,
                           float momentum, float* out, int N, int D, int H, int W, int C, void* ws, size_t ws_bytes,
-                          hipStream_t s);
+                          hipStream_t s, void* out_bf16 = nullptr);
 int stem_bnact_bwd_launch(const float* dout, const float* x, const float* w, const float* bias, const float* mean,
                           const float* var, const float* gamma, const float* beta, const uint8_t* keep,
                           const PhiloxMask& rk, float p, float slope, float eps, float* dy, float* dgamma,
@@ -181,7 +181,7 @@ int stem_bnact_bwd_launch(const float* dout, const float* x, const float* w, con
                           hipStream_t s);
 bool k3_thin_bn_fwd_supported(int N, int D, int H, int W, int Cin);
 int k3_thin_bn_fwd_launch(const float* x, const BnPrologue& bn, const float* w, const float* bias, float* out,
-                          int N, int D, int H, int W, int Cin, hipStream_t s);
+                          int N, int D, int H, int W, int Cin, hipStream_t s, void* x_bf16 = nullptr);
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -414,6 +414,13 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
 extern "C" int siv_conv1_bnact_supported(int Cout) {
     return conv_path() != 1 && Cout % 4 == 0 && Cout >= 4 && Cout <= 64 ? 1 : 0;
 }
+extern "C" int siv_conv1_bnact_fwd_bf16(const float* x, const float* w, const float* bias, const float* gamma,
+                                        const float* beta, const uint8_t* keep, uint64_t mask_seed,
+                                        uint64_t mask_stream_id, const uint64_t* mask_epoch, float p, float slope,
+                                        float eps, int train, float* mean, float* var, float* running_mean,
+                                        float* running_var, int64_t* num_batches_tracked, float momentum,
+                                        float* out, void* out_bf16, int N, int D, int H, int W, int Cout, void* ws,
+                                        size_t ws_bytes, siv_stream_t stream);
 extern "C" int siv_conv1_bnact_fwd(const float* x, const float* w, const float* bias, const float* gamma,
                                    const float* beta, const uint8_t* keep, uint64_t mask_seed,
                                    uint64_t mask_stream_id, const uint64_t* mask_epoch, float p, float slope,
@@ -421,6 +428,18 @@ extern "C" int siv_conv1_bnact_fwd(const float* x, const float* w, const float* 
                                    float* running_var, int64_t* num_batches_tracked, float momentum,
                                    float* out, int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes,
                                    siv_stream_t stream) {
+    return siv_conv1_bnact_fwd_bf16(x, w, bias, gamma, beta, keep, mask_seed, mask_stream_id, mask_epoch, p, slope, eps,
+                                    train, mean, var, running_mean, running_var, num_batches_tracked, momentum, out,
+                                    nullptr, N, D, H, W, Cout, ws, ws_bytes, stream);
+}
+extern "C" int siv_conv1_bnact_fwd_bf16(const float* x, const float* w, const float* bias, const float* gamma,
+                                        const float* beta, const uint8_t* keep, uint64_t mask_seed,
+                                        uint64_t mask_stream_id, const uint64_t* mask_epoch, float p, float slope,
+                                        float eps, int train, float* mean, float* var, float* running_mean,
+                                        float* running_var, int64_t* num_batches_tracked, float momentum,
+                                        float* out, void* out_bf16, int N, int D, int H, int W, int Cout, void* ws,
+                                        size_t ws_bytes, siv_stream_t stream) {
+    SIV_CHECK_ARG(((uintptr_t)out_bf16 & 7) == 0, "conv1_bnact_fwd: the bf16 copy must be 8-byte aligned");
     SIV_CHECK_ARG(x && w && gamma && beta && mean && var && out, "conv1_bnact_fwd: null pointer");
     int rc = check_conv_shape("conv1_bnact_fwd", N, D, H, W, 1, Cout, 1);
     if (rc) return rc;
@@ -434,7 +453,7 @@ extern "C" int siv_conv1_bnact_fwd(const float* x, const float* w, const float* 
     const PhiloxMask rk{mask_seed, mask_stream_id, (const unsigned long long*)mask_epoch, keep == nullptr && p > 0.f};
     return stem_bnact_fwd_launch(x, w, bias, gamma, beta, keep, rk, p, slope, eps, train, mean, var, running_mean,
                                  running_var, num_batches_tracked, momentum, out, N, D, H, W, Cout, ws, ws_bytes,
-                                 (hipStream_t)stream);
+                                 (hipStream_t)stream, out_bf16);
 }
 extern "C" int siv_conv1_bnact_bwd(const float* dout, const float* x, const float* w, const float* bias,
                                    const float* mean, const float* var, const float* gamma, const float* beta,
@@ -460,23 +479,31 @@ extern "C" int siv_conv1_bnact_bwd(const float* dout, const float* x, const floa
 extern "C" int siv_bnact_conv3d_k3_to1_supported(int N, int D, int H, int W, int Cin) {
     return conv_path() != 1 && k3_thin_bn_fwd_supported(N, D, H, W, Cin) ? 1 : 0;
 }
+extern "C" int siv_bnact_conv3d_k3_to1_fwd_bf16(const float* x, const float* mean, const float* var,
+                                                const float* gamma, const float* beta, float eps, float slope,
+                                                const float* w, const float* bias, float* y, void* x_bf16, int N,
+                                                int D, int H, int W, int Cin, siv_stream_t stream) {
+    SIV_CHECK_ARG(x && mean && var && gamma && beta && w && y, "bnact_conv3d_k3_to1_fwd: null pointer");
+    int rc = check_conv_shape("bnact_conv3d_k3_to1_fwd", N, D, H, W, Cin, 1, 1);
+    if (rc) return rc;
+    SIV_CHECK_ARG(aligned16(x) && aligned16(w) && ((uintptr_t)x_bf16 & 7) == 0,
+                  "bnact_conv3d_k3_to1_fwd: x and w must be 16-byte aligned, the bf16 copy 8-byte aligned");
+    SIV_PICK("thin");
+    return k3_thin_bn_fwd_launch(x, BnPrologue{mean, var, gamma, beta, eps, slope}, w, bias, y, N, D, H, W, Cin,
+                                 (hipStream_t)stream, x_bf16);
+}
 extern "C" int siv_bnact_conv3d_k3_to1_fwd(const float* x, const float* mean, const float* var,
                                            const float* gamma, const float* beta, float eps, float slope,
                                            const float* w, const float* bias, float* y, int N, int D, int H,
                                            int W, int Cin, siv_stream_t stream) {
-    SIV_CHECK_ARG(x && mean && var && gamma && beta && w && y, "bnact_conv3d_k3_to1_fwd: null pointer");
-    int rc = check_conv_shape("bnact_conv3d_k3_to1_fwd", N, D, H, W, Cin, 1, 1);
-    if (rc) return rc;
-    SIV_CHECK_ARG(aligned16(x) && aligned16(w), "bnact_conv3d_k3_to1_fwd: x and w must be 16-byte aligned");
-    SIV_PICK("thin");
-    return k3_thin_bn_fwd_launch(x, BnPrologue{mean, var, gamma, beta, eps, slope}, w, bias, y, N, D, H, W, Cin,
-                                 (hipStream_t)stream);
+    return siv_bnact_conv3d_k3_to1_fwd_bf16(x, mean, var, gamma, beta, eps, slope, w, bias, y, nullptr, N, D, H, W, Cin,
+                                            stream);
 }
-extern "C" int siv_bnact_conv3d_k3_to1_wgrad(const float* x, const float* mean, const float* var,
-                                             const float* gamma, const float* beta, float eps, float slope,
-                                             const float* dy, float* dw, float* dbias, int N, int D, int H,
-                                             int W, int Cin, int accumulate, void* ws, size_t ws_bytes,
-                                             siv_stream_t stream) {
+static int to1_wgrad_impl(const float* x, bool x_bf16, const float* mean, const float* var,
+                          const float* gamma, const float* beta, float eps, float slope,
+                          const float* dy, float* dw, float* dbias, int N, int D, int H,
+                          int W, int Cin, int accumulate, void* ws, size_t ws_bytes,
+                          siv_stream_t stream) {
     SIV_CHECK_ARG(x && mean && var && gamma && beta && dy && dw, "bnact_conv3d_k3_to1_wgrad: null pointer");
     int rc = check_conv_shape("bnact_conv3d_k3_to1_wgrad", N, D, H, W, Cin, 1, 1);
     if (rc) return rc;
@@ -485,14 +512,30 @@ extern "C" int siv_bnact_conv3d_k3_to1_wgrad(const float* x, const float* mean, 
     const BnPrologue bn{mean, var, gamma, beta, eps, slope};
     SIV_PICK("thin");
     return k3_thin_wgrad_launch(x, dy, dw, dbias, N, D, H, W, Cin, 1, accumulate, ws, ws_bytes,
-                                (hipStream_t)stream, &bn);
+                                (hipStream_t)stream, &bn, x_bf16);
+}
+extern "C" int siv_bnact_conv3d_k3_to1_wgrad(const float* x, const float* mean, const float* var,
+                                             const float* gamma, const float* beta, float eps, float slope,
+                                             const float* dy, float* dw, float* dbias, int N, int D, int H,
+                                             int W, int Cin, int accumulate, void* ws, size_t ws_bytes,
+                                             siv_stream_t stream) {
+    return to1_wgrad_impl(x, false, mean, var, gamma, beta, eps, slope, dy, dw, dbias, N, D, H, W, Cin, accumulate, ws,
+                          ws_bytes, stream);
+}
+extern "C" int siv_bnact_conv3d_k3_to1_wgrad_bf16(const void* x_bf16, const float* mean, const float* var,
+                                                  const float* gamma, const float* beta, float eps, float slope,
+                                                  const float* dy, float* dw, float* dbias, int N, int D, int H,
+                                                  int W, int Cin, int accumulate, void* ws, size_t ws_bytes,
+                                                  siv_stream_t stream) {
+    return to1_wgrad_impl((const float*)x_bf16, true, mean, var, gamma, beta, eps, slope, dy, dw, dbias, N, D, H, W, Cin,
+                          accumulate, ws, ws_bytes, stream);
 }
 
-extern "C" int siv_bnact_conv3d_k3_to1_dgrad(const float* dy, const float* w, const float* x,
-                                             const float* mean, const float* var, const float* gamma,
-                                             const float* beta, float eps, float slope, float* dx,
-                                             float* dgamma, float* dbeta, int accumulate, int N, int D, int H,
-                                             int W, int Cin, void* ws, size_t ws_bytes, siv_stream_t stream) {
+static int to1_dgrad_impl(const float* dy, const float* w, const float* x, bool x_bf16,
+                          const float* mean, const float* var, const float* gamma,
+                          const float* beta, float eps, float slope, float* dx,
+                          float* dgamma, float* dbeta, int accumulate, int N, int D, int H,
+                          int W, int Cin, void* ws, size_t ws_bytes, siv_stream_t stream) {
     SIV_CHECK_ARG(dy && w && x && mean && var && gamma && beta && dx, "bnact_conv3d_k3_to1_dgrad: null pointer");
     int rc = check_conv_shape("bnact_conv3d_k3_to1_dgrad", N, D, H, W, Cin, 1, 1);
     if (rc) return rc;
@@ -502,7 +545,23 @@ extern "C" int siv_bnact_conv3d_k3_to1_dgrad(const float* dy, const float* w, co
                   "bnact_conv3d_k3_to1_dgrad: x, dx and the workspace must be 16-byte aligned");
     SIV_PICK("thin");
     return k3_thin_bn_dgrad_launch(dy, w, x, BnPrologue{mean, var, gamma, beta, eps, slope}, dx, dgamma, dbeta,
-                                   accumulate, N, D, H, W, Cin, ws, ws_bytes, (hipStream_t)stream);
+                                   accumulate, N, D, H, W, Cin, ws, ws_bytes, (hipStream_t)stream, x_bf16);
+}
+extern "C" int siv_bnact_conv3d_k3_to1_dgrad(const float* dy, const float* w, const float* x,
+                                             const float* mean, const float* var, const float* gamma,
+                                             const float* beta, float eps, float slope, float* dx,
+                                             float* dgamma, float* dbeta, int accumulate, int N, int D, int H,
+                                             int W, int Cin, void* ws, size_t ws_bytes, siv_stream_t stream) {
+    return to1_dgrad_impl(dy, w, x, false, mean, var, gamma, beta, eps, slope, dx, dgamma, dbeta, accumulate, N, D, H, W,
+                          Cin, ws, ws_bytes, stream);
+}
+extern "C" int siv_bnact_conv3d_k3_to1_dgrad_bf16(const float* dy, const float* w, const void* x_bf16,
+                                                  const float* mean, const float* var, const float* gamma,
+                                                  const float* beta, float eps, float slope, float* dx,
+                                                  float* dgamma, float* dbeta, int accumulate, int N, int D, int H,
+                                                  int W, int Cin, void* ws, size_t ws_bytes, siv_stream_t stream) {
+    return to1_dgrad_impl(dy, w, (const float*)x_bf16, true, mean, var, gamma, beta, eps, slope, dx, dgamma, dbeta,
+                          accumulate, N, D, H, W, Cin, ws, ws_bytes, stream);
 }
 
 // Input gradient of the 3x3x3 convolution = forward convolution of dy with the flipped, transposed

@@ -32,6 +32,12 @@ SIGNATURES = {
                             _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_conv1_bnact_bwd": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _u64, _u64, _f, _fl, _fl, _fl, _f, _f, _f, _i,
                             _i, _i, _i, _i, _i, _f, _sz, _f],
+    "siv_conv1_bnact_fwd_bf16": [_f, _f, _f, _f, _f, _f, _u64, _u64, _f, _fl, _fl, _fl, _i, _f, _f, _f, _f, _f, _fl, _f,
+                                 _f, _i, _i, _i, _i, _i, _f, _sz, _f],
+    "siv_bnact_conv3d_k3_to1_fwd_bf16": [_f, _f, _f, _f, _f, _fl, _fl, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f],
+    "siv_bnact_conv3d_k3_to1_dgrad_bf16": [_f, _f, _f, _f, _f, _f, _f, _fl, _fl, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f,
+                                           _sz, _f],
+    "siv_bnact_conv3d_k3_to1_wgrad_bf16": [_f, _f, _f, _f, _f, _fl, _fl, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_bnact_conv3d_k3_to1_supported": [_i, _i, _i, _i, _i],
     "siv_bnact_conv3d_k3_to1_fwd": [_f, _f, _f, _f, _f, _fl, _fl, _f, _f, _f, _i, _i, _i, _i, _i, _f],
     "siv_bnact_conv3d_k3_to1_dgrad": [_f, _f, _f, _f, _f, _f, _f, _fl, _fl, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f, _sz, _f],

@@ -16,6 +16,7 @@ encoder / decoder passes (their gradients are differences of nearly equal number
 """
 import contextlib
 import functools
+import os
 
 import torch
 
@@ -58,6 +59,7 @@ class _Packed:
 
 
 _depth = 0      # > 0 inside an encoder / decoder forward pass (``scoped``)
+NATIVE = os.environ.get("SIV_BF16_NATIVE", "1") != "0"     # 0: every kept tensor goes through the conversion hooks
 
 
 def native() -> bool:
@@ -65,7 +67,7 @@ def native() -> bool:
     storage is on, an encoder / decoder pass is running and autograd is recording.  (BatchNorm + activation
     emits the copies of its input and output in its own pass and reads the bf16 input in its backward pass;
     everything else goes through the saved-tensor hooks below.)"""
-    return _storage == "bf16" and _depth > 0 and torch.is_grad_enabled()
+    return _storage == "bf16" and _depth > 0 and torch.is_grad_enabled() and NATIVE
 
 
 def count_native(*tensors) -> None:

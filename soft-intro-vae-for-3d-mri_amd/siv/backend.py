@@ -239,8 +239,9 @@ class HipBackend:
         return None, (keep.seed & m, keep.stream_id & m, keep.epoch)
 
     def conv1_bnact_fwd(self, x, w, bias, gamma, beta, keep, p, slope, eps, train: bool, running_mean,
-                        running_var, nbt, momentum: float):
-        """Returns (out, mean, var); in evaluation mode mean / var are the running statistics."""
+                        running_var, nbt, momentum: float, emit_bf16: bool = False):
+        """Returns (out, mean, var); in evaluation mode mean / var are the running statistics.  ``emit_bf16``:
+        (out, mean, var, bf16 copy of out), the copy written by the same pass."""
         masked = keep is not None       # the C entry point reads "no mask tensor, p > 0" as "draw the mask"
         keep, mk = self._mask_args(keep)
         self._check_dev(x, w, bias, gamma, beta, keep, mk[2], running_mean, running_var, nbt)
@@ -255,12 +256,13 @@ class HipBackend:
         else:
             mean, var, rm, rv, nb = running_mean, running_var, None, None, None
         ws, wsb = self._workspace(x)
-        _lib.check(self.lib.siv_conv1_bnact_fwd(_p(x), _p(w), _p(bias), _p(gamma), _p(beta), _p(keep), mk[0], mk[1],
-                                                _p(mk[2]), float(p) if masked else 0.0, float(slope), float(eps),
-                                                int(train), _p(mean), _p(var), _p(rm),
-                                                _p(rv), _p(nb), float(momentum), _p(out), N, D, H, W, C, ws, wsb,
-                                                self._stream(x)), "siv_conv1_bnact_fwd")
-        return out, mean, var
+        oh = torch.empty_like(out, dtype=torch.bfloat16) if emit_bf16 else None
+        _lib.check(self.lib.siv_conv1_bnact_fwd_bf16(_p(x), _p(w), _p(bias), _p(gamma), _p(beta), _p(keep), mk[0],
+                                                     mk[1], _p(mk[2]), float(p) if masked else 0.0, float(slope),
+                                                     float(eps), int(train), _p(mean), _p(var), _p(rm),
+                                                     _p(rv), _p(nb), float(momentum), _p(out), _p(oh), N, D, H, W, C,
+                                                     ws, wsb, self._stream(x)), "siv_conv1_bnact_fwd")
+        return (out, mean, var, oh) if emit_bf16 else (out, mean, var)
 
     def conv1_bnact_bwd(self, dout, x, w, bias, mean, var, gamma, beta, keep, p, slope, eps,
                         want_affine: bool, dgamma_out=None, dbeta_out=None):
@@ -294,24 +296,30 @@ class HipBackend:
         N, C, D, H, W = x.shape
         return bool(self.lib.siv_bnact_conv3d_k3_to1_supported(N, D, H, W, C))
 
-    def bnact_conv_to1_fwd(self, x, mean, var, gamma, beta, eps: float, slope: float, w, bias):
+    def bnact_conv_to1_fwd(self, x, mean, var, gamma, beta, eps: float, slope: float, w, bias,
+                           emit_bf16: bool = False):
+        """``emit_bf16``: returns (y, bf16 copy of x), the copy written by the same pass; the backward calls
+        below take that copy in place of ``x``."""
         self._check_dev(x, mean, var, gamma, beta, w, bias)
         x, w = cl(x), cl(w)
         N, C, D, H, W = x.shape
         assert tuple(w.shape) == (1, C, 3, 3, 3), tuple(w.shape)
         y = empty_cl((N, 1, D, H, W), x)
-        _lib.check(self.lib.siv_bnact_conv3d_k3_to1_fwd(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), eps, slope,
-                                                        _p(w), _p(bias), _p(y), N, D, H, W, C, self._stream(x)),
+        xh = torch.empty_like(x, dtype=torch.bfloat16) if emit_bf16 else None
+        _lib.check(self.lib.siv_bnact_conv3d_k3_to1_fwd_bf16(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), eps, slope,
+                                                             _p(w), _p(bias), _p(y), _p(xh), N, D, H, W, C,
+                                                             self._stream(x)),
                    "siv_bnact_conv3d_k3_to1_fwd")
-        return y
+        return (y, xh) if emit_bf16 else y
 
     def bnact_conv_to1_dgrad(self, dy, w, x, mean, var, gamma, beta, eps: float, slope: float,
                              want_affine: bool, dgamma_out=None, dbeta_out=None):
         """Gradient of the raw tensor ``x`` (and of gamma / beta: returned, or ADDED into the given buffers)."""
-        self._check_dev(dy, w, x, mean, var, gamma, beta, dgamma_out, dbeta_out)
+        x_bf16 = x.dtype == torch.bfloat16
+        self._check_dev(dy, w, None if x_bf16 else x, mean, var, gamma, beta, dgamma_out, dbeta_out)
         dy, w, x = cl(dy), cl(w), cl(x)
         N, C, D, H, W = x.shape
-        dx = like(x)
+        dx = empty_cl(tuple(x.shape), dy)
         acc = 0
         if want_affine and dgamma_out is not None:
             assert dbeta_out is not None and dgamma_out.is_contiguous() and dbeta_out.is_contiguous()
@@ -320,22 +328,25 @@ class HipBackend:
             dgamma = torch.empty(C, device=x.device, dtype=torch.float32) if want_affine else None
             dbeta = torch.empty(C, device=x.device, dtype=torch.float32) if want_affine else None
         ws, wsb = self._workspace(x)
-        _lib.check(self.lib.siv_bnact_conv3d_k3_to1_dgrad(_p(dy), _p(w), _p(x), _p(mean), _p(var), _p(gamma),
-                                                          _p(beta), eps, slope, _p(dx), _p(dgamma), _p(dbeta), acc,
-                                                          N, D, H, W, C, ws, wsb, self._stream(x)),
+        fn = self.lib.siv_bnact_conv3d_k3_to1_dgrad_bf16 if x_bf16 else self.lib.siv_bnact_conv3d_k3_to1_dgrad
+        _lib.check(fn(_p(dy), _p(w), _p(x), _p(mean), _p(var), _p(gamma),
+                      _p(beta), eps, slope, _p(dx), _p(dgamma), _p(dbeta), acc,
+                      N, D, H, W, C, ws, wsb, self._stream(x)),
                    "siv_bnact_conv3d_k3_to1_dgrad")
         return dx, dgamma, dbeta
 
     def bnact_conv_to1_wgrad(self, x, mean, var, gamma, beta, eps: float, slope: float, dy,
                              want_bias: bool = False, dw_out=None, db_out=None):
-        self._check_dev(x, mean, var, gamma, beta, dy, dw_out, db_out)
+        x_bf16 = x.dtype == torch.bfloat16
+        self._check_dev(None if x_bf16 else x, mean, var, gamma, beta, dy, dw_out, db_out)
         x, dy = cl(x), cl(dy)
         N, C, D, H, W = x.shape
         dw, db, acc = self._grad_targets((1, C, 3, 3, 3), dy, want_bias, dw_out, db_out)
         ws, wsb = self._workspace(dy)
-        _lib.check(self.lib.siv_bnact_conv3d_k3_to1_wgrad(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), eps, slope,
-                                                          _p(dy), _p(dw), _p(db), N, D, H, W, C, acc, ws, wsb,
-                                                          self._stream(dy)),
+        fn = self.lib.siv_bnact_conv3d_k3_to1_wgrad_bf16 if x_bf16 else self.lib.siv_bnact_conv3d_k3_to1_wgrad
+        _lib.check(fn(_p(x), _p(mean), _p(var), _p(gamma), _p(beta), eps, slope,
+                      _p(dy), _p(dw), _p(db), N, D, H, W, C, acc, ws, wsb,
+                      self._stream(dy)),
                    "siv_bnact_conv3d_k3_to1_wgrad")
         return dw, db
 

@@ -108,11 +108,11 @@ class _Conv3dK3(Function):
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         want_w = ctx.needs_input_grad[1] or want_b
         direct = ctx.needs_input_grad[1] and ctx.w_buf is not None and (not want_b or ctx.b_buf is not None)
+        if want_w and x.dtype == torch.bfloat16:
+            x = B.from_bf16(x)          # before the event the side-stream weight gradient waits for
         ready = _side_ready(B, dy) if direct else None
         if ctx.needs_input_grad[0]:
             dx = B.conv3d_k3_dgrad(dy, w, ctx.ups)
-        if want_w and x.dtype == torch.bfloat16:
-            x = B.from_bf16(x)
         if direct:
             _wgrad_on_side_stream(B, x, dy, ready,
                                   lambda: B.conv3d_k3_wgrad(x, dy, ctx.ups, want_b, ctx.w_buf, ctx.b_buf))
@@ -265,6 +265,7 @@ class _BnAct(Function):
             activations.count_native(y, out)
             y = yh
             ctx.mark_non_differentiable(oh)
+            ctx.set_materialize_grads(False)        # no zero "gradient" tensor for the bf16 copy
         else:
             out = B.bn_act_fwd(y, mean, var, gamma, beta, res, keep, p, slope, pool, bn.eps, **dst)
         ctx.save_for_backward(y, mean, var, gamma, beta, res, keep)
@@ -274,6 +275,8 @@ class _BnAct(Function):
 
     @staticmethod
     def backward(ctx, dout, d_oh=None):
+        if dout is None:
+            return (None,) * 14
         y, mean, var, gamma, beta, res, keep = ctx.saved_tensors        # y: fp32, or its bf16 copy
         p, slope, pool, eps, train = ctx.cfg
         if not train:
@@ -406,19 +409,28 @@ class _Conv1BnAct(Function):
     ordinary weight / input gradient kernels of the convolution."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, gamma, beta, keep, bn, p, slope, train):
+    def forward(ctx, x, w, bias, gamma, beta, keep, bn, p, slope, train, emit_bf16=False):
         B = get_backend()
-        out, mean, var = B.conv1_bnact_fwd(x, w, bias, gamma, beta, keep, p, slope, bn.eps, train,
-                                           bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                           BN_MOMENTUM if bn.momentum is None else bn.momentum)
+        res = B.conv1_bnact_fwd(x, w, bias, gamma, beta, keep, p, slope, bn.eps, train,
+                                bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                BN_MOMENTUM if bn.momentum is None else bn.momentum,
+                                **({"emit_bf16": True} if emit_bf16 else {}))
+        out, mean, var = res[:3]
+        oh = res[3] if emit_bf16 else None      # bf16 copy of the output, for the convolution that consumes it
+        if oh is not None:
+            activations.count_native(out)
+            ctx.mark_non_differentiable(oh)
+            ctx.set_materialize_grads(False)        # no zero "gradient" tensor for the bf16 copy
         ctx.mask_key = None if keep is None or torch.is_tensor(keep) else keep   # a mask drawn in-kernel
         ctx.save_for_backward(x, w, bias, mean, var, gamma, beta, keep if ctx.mask_key is None else None)
         ctx.cfg = (p, slope, bn.eps, train)
         ctx.bufs = (_grad_buf(w), _grad_buf(bias), _grad_buf(gamma), _grad_buf(beta))
-        return out
+        return out, oh
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, d_oh=None):
+        if dout is None:
+            return (None,) * 11
         x, w, bias, mean, var, gamma, beta, keep = ctx.saved_tensors
         if ctx.mask_key is not None:
             keep = ctx.mask_key
@@ -448,7 +460,7 @@ class _Conv1BnAct(Function):
         if ctx.needs_input_grad[0]:
             dx = B.conv3d_k3_dgrad(dy, w, 1)
         return (dx, dw, dcb, dg if ctx.needs_input_grad[3] else None, db if ctx.needs_input_grad[4] else None,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 def conv1_bn_act_supported(x, conv) -> bool:
@@ -461,7 +473,11 @@ def conv1_bn_act(x, conv, bn, slope: float, keep=None, p: float = 0.0, train: bo
     """``dropout(LeakyReLU(bn(conv(x))))`` for a single-channel input as one operator (see
     ``conv1_bn_act_supported``); the fallback is ``conv_bn_act``.  ``keep`` is a uint8 mask tensor or a
     ``rng.PhiloxKeep`` key, for which the kernels draw the mask themselves."""
-    return _Conv1BnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, keep, bn, p, slope, train)
+    emit = train and activations.native() and x.numel() * conv.out_channels >= activations.MIN_NUMEL
+    o, oh = _Conv1BnAct.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, keep, bn, p, slope, train, emit)
+    if oh is not None:
+        o._siv_bf16 = oh
+    return o
 
 
 class _BnActConvTo1(Function):
@@ -471,10 +487,17 @@ class _BnActConvTo1(Function):
     input gradient and BatchNorm's own backward."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, w, bias, bn, slope, train, stats):
+    def forward(ctx, y, gamma, beta, w, bias, bn, slope, train, stats, emit_bf16=False):
         B = get_backend()
         mean, var = stats if train else (bn.running_mean, bn.running_var)
-        out = B.bnact_conv_to1_fwd(y, mean, var, gamma, beta, bn.eps, slope, w, bias)
+        if emit_bf16:
+            # bf16 activation storage: the forward pass writes the bf16 copy of y, which is all the backward
+            # passes read
+            out, yh = B.bnact_conv_to1_fwd(y, mean, var, gamma, beta, bn.eps, slope, w, bias, emit_bf16=True)
+            activations.count_native(y)
+            y = yh
+        else:
+            out = B.bnact_conv_to1_fwd(y, mean, var, gamma, beta, bn.eps, slope, w, bias)
         ctx.save_for_backward(y, mean, var, gamma, beta, w)
         ctx.cfg = (slope, bn.eps, train, bias is not None)
         ctx.bufs = (_grad_buf(gamma), _grad_buf(beta), _grad_buf(w), _grad_buf(bias))
@@ -510,7 +533,7 @@ class _BnActConvTo1(Function):
             if not ctx.needs_input_grad[0]:
                 dy = None
         return (dy, dg if ctx.needs_input_grad[1] else None, db if ctx.needs_input_grad[2] else None, dw, dcb,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 def bn_act_conv_to1_supported(y) -> bool:
@@ -525,7 +548,8 @@ def bn_act_conv_to1(y, bn, slope: float, conv, train: bool = True, stats=None):
         B = get_backend()
         stats = B.bn_stats(y, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                            BN_MOMENTUM if bn.momentum is None else bn.momentum)
-    return _BnActConvTo1.apply(y, bn.weight, bn.bias, conv.weight, conv.bias, bn, slope, train, stats)
+    emit = train and activations.native() and y.numel() >= activations.MIN_NUMEL
+    return _BnActConvTo1.apply(y, bn.weight, bn.bias, conv.weight, conv.bias, bn, slope, train, stats, emit)
 
 
 def conv_with_stats(x, conv, bn, ups: int = 1, train: bool = True):

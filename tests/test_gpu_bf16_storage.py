@@ -185,3 +185,48 @@ def test_bn_act_bf16_entry_points(c, dims, n, groups, pool, use_res, p):
     g6 = torch.ones(6, device="cuda")
     with pytest.raises(L.SivError):                        # no float4 kernel for 6 channels: no bf16 copies
         B.bn_act_fwd(y6, m6, v6, g6, g6, None, None, 0.0, 0.2, 1, 1e-5, emit_bf16=True)
+
+
+def test_fused_stem_and_output_layer_bf16_entry_points():
+    """The fused encoder stem writes the bf16 copy of its output beside it (siv_conv1_bnact_fwd_bf16); the fused
+    decoder end (BatchNorm + LeakyReLU inside the 64 -> 1 convolution) writes the bf16 copy of the raw tensor it
+    normalises (siv_bnact_conv3d_k3_to1_fwd_bf16) and both of its backward operators read that copy
+    (..._dgrad_bf16, ..._wgrad_bf16).  Copies: bit-identical to torch's rounding, every voxel written once;
+    backward from the copy: bit-identical to the fp32-reading kernels fed the expanded copy."""
+    import siv.backend as sb
+    B = sb.get_backend()
+    gen = torch.Generator().manual_seed(77)
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last_3d)
+    # ---- stem: Conv3d(1, 64, 3) -> BatchNorm -> LeakyReLU -> Dropout
+    n, dims, C = 2, (12, 20, 18), 64
+    x = torch.rand(n, 1, *dims, generator=gen).cuda()
+    w = cl(torch.randn(C, 1, 3, 3, 3, generator=gen) * 0.3)
+    bias, gamma, beta = (torch.randn(C, generator=gen) * 0.1).cuda(), (1 + 0.2 * torch.randn(C, generator=gen)).cuda(), \
+        (0.1 * torch.randn(C, generator=gen)).cuda()
+    keep = cl((torch.rand(n, C, *dims, generator=gen) >= 0.35).to(torch.uint8))
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    out, mean, var = B.conv1_bnact_fwd(x, w, bias, gamma, beta, keep, 0.35, 0.2, 1e-5, True, rm.clone(), rv.clone(),
+                                       None, 0.1)
+    out2, mean2, var2, oh = B.conv1_bnact_fwd(x, w, bias, gamma, beta, keep, 0.35, 0.2, 1e-5, True, rm.clone(),
+                                              rv.clone(), None, 0.1, emit_bf16=True)
+    assert torch.equal(out, out2) and torch.equal(mean, mean2) and torch.equal(var, var2)
+    assert oh.dtype == torch.bfloat16 and oh.stride() == out.stride() and torch.equal(oh, out.to(torch.bfloat16))
+    # ---- decoder end: BatchNorm -> LeakyReLU -> Conv3d(64, 1, 3) on a raw 64-channel tensor
+    n, dims = 2, (18, 24, 35)                      # a partial 16-wide column, several z segments
+    y = cl(torch.randn(n, C, *dims, generator=gen) * 1.5 + 0.2)
+    w1 = cl(torch.randn(1, C, 3, 3, 3, generator=gen) * 0.05)
+    b1 = torch.randn(1, generator=gen).cuda()
+    dout = cl(torch.randn(n, 1, *dims, generator=gen))
+    assert B.bnact_conv_to1_supported(y)
+    m, v = B.bn_stats(y, None, None, None, 0.1)
+    o1 = B.bnact_conv_to1_fwd(y, m, v, gamma, beta, 1e-5, 0.2, w1, b1)
+    o2, yh = B.bnact_conv_to1_fwd(y, m, v, gamma, beta, 1e-5, 0.2, w1, b1, emit_bf16=True)
+    assert torch.equal(o1, o2)
+    assert yh.dtype == torch.bfloat16 and yh.stride() == y.stride() and torch.equal(yh, y.to(torch.bfloat16))
+    yx = yh.float()
+    dx, dg, db = B.bnact_conv_to1_dgrad(dout, w1, yh, m, v, gamma, beta, 1e-5, 0.2, True)
+    dx1, dg1, db1 = B.bnact_conv_to1_dgrad(dout, w1, yx, m, v, gamma, beta, 1e-5, 0.2, True)
+    assert torch.equal(dx, dx1) and torch.equal(dg, dg1) and torch.equal(db, db1)
+    dw, dcb = B.bnact_conv_to1_wgrad(yh, m, v, gamma, beta, 1e-5, 0.2, dout, True)
+    dw1, dcb1 = B.bnact_conv_to1_wgrad(yx, m, v, gamma, beta, 1e-5, 0.2, dout, True)
+    assert torch.equal(dw, dw1) and torch.equal(dcb, dcb1)
