@@ -890,7 +890,7 @@ __device__ __forceinline__ float bn_act1(float x, float a, float b, float slope)
 // tensor).  The activated tensor is then never written or read.
 // a_bf16 (optional): a bf16 copy of the operand, written by the block that owns a voxel (the interior of its
 // column, its own z range) from the very values it loaded.
-template <int KG, bool BN>
+template <int KG, bool BN, bool EMIT = false>
 __global__ __launch_bounds__(256, 2) void c_to_one_zwalk12_k(const float* __restrict__ a,
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ bias,
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256, 2) void c_to_one_zwalk12_k(const float* __rest
         own[q] = okv[q] && hy >= 1 && hy <= ZX_H && hx >= 1 && hx <= ZX_W;     // not a halo voxel of this column
         off[q] = okv[q] ? (gy * W + gx) * C + 4 * h : 0;
     }
-    uint16_t* an16 = a_bf16 ? a_bf16 + (long)n * D * H * W * C : nullptr;
+    uint16_t* an16 = EMIT ? a_bf16 + (long)n * D * H * W * C : nullptr;
     const float* an = a + (long)n * D * H * W * C;
     float4 av[2][2][KG];
     auto load_plane = [&](float4 (&dst)[2][KG], int z) {
@@ -968,6 +968,32 @@ __global__ __launch_bounds__(256, 2) void c_to_one_zwalk12_k(const float* __rest
 #pragma unroll
         for (int par = 0; par < 2; ++par) {
             const int z = zz + par;
+            // (the stores of the bf16 copy go out BEFORE the next plane's loads are issued: loads and stores share
+            // one in-order counter, and a store behind those loads would make every later wait for them a wait
+            // for everything)
+            if (EMIT && z >= zlo && z < zhi) {         // the raw values of the voxels this block owns, as bf16
+                // Lanes i and i + 32 hold the two channel quads of a voxel's 8-channel group.  They swap one
+                // quad of every pair of groups, so that each stores 8 channels = 16 contiguous bytes (lane h = 0
+                // group g, lane h = 1 group g + 1): half as many, twice as wide store requests per voxel.
+                uint16_t* pl16 = an16 + (long)z * H * W * C;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int g = 0; g < KG; g += 2) {
+                        const float4 a4 = av[par][q][g], b4 = av[par][q][g + 1];
+                        const float4 send = h ? a4 : b4;
+                        float4 recv;
+                        recv.x = __shfl_xor(send.x, 32, 64); recv.y = __shfl_xor(send.y, 32, 64);
+                        recv.z = __shfl_xor(send.z, 32, 64); recv.w = __shfl_xor(send.w, 32, 64);
+                        const float4 lo = h ? recv : a4, hi = h ? b4 : recv;
+                        if (own[q]) {
+                            uint4 o;
+                            o.x = bf16_rne(lo.x) | (bf16_rne(lo.y) << 16); o.y = bf16_rne(lo.z) | (bf16_rne(lo.w) << 16);
+                            o.z = bf16_rne(hi.x) | (bf16_rne(hi.y) << 16); o.w = bf16_rne(hi.z) | (bf16_rne(hi.w) << 16);
+                            *reinterpret_cast<uint4*>(pl16 + off[q] - 4 * h + 8 * (g + h)) = o;
+                        }
+                    }
+            }
             load_plane(av[par ^ 1], z + 1);
             __builtin_amdgcn_sched_barrier(0);          // keep the loads ahead of the products
             float* pz = pim[par];
@@ -978,14 +1004,6 @@ __global__ __launch_bounds__(256, 2) void c_to_one_zwalk12_k(const float* __rest
                 for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
             const bool zin = z >= 0 && z < D;
             const bool ok0 = zin && okv[0], ok1 = zin && okv[1];
-            if (an16 && z >= zlo && z < zhi) {         // the raw values of the voxels this block owns, as bf16
-                uint16_t* pl16 = an16 + (long)z * H * W * C;
-#pragma unroll
-                for (int g = 0; g < KG; ++g) {
-                    if (own[0]) thin_st_bf4(pl16, off[0] + 8 * g, av[par][0][g]);
-                    if (own[1]) thin_st_bf4(pl16, off[1] + 8 * g, av[par][1][g]);
-                }
-            }
 #pragma unroll
             for (int g = 0; g < KG; ++g) {              // the two row tiles alternate: independent chains
                 float4 v0 = av[par][0][g], v1 = av[par][1][g];
@@ -1326,8 +1344,12 @@ int k3_thin_bn_fwd_launch(const float* x, const BnPrologue& bn, const float* w, 
         set_error("bnact_conv3d_k3_to1: unsupported shape (needs 64 channels, D >= 16, H >= 12, W >= 16)");
         return SIV_EINVAL;
     }
-    c_to_one_zwalk12_k<8, true><<<(unsigned)zx.nb, 256, 0, s>>>(x, w, bias, out, N, D, H, W, 0, zx.nth, zx.ntw,
-                                                               zx.zsplit, bn, (uint16_t*)x_bf16);
+    if (x_bf16)
+        c_to_one_zwalk12_k<8, true, true><<<(unsigned)zx.nb, 256, 0, s>>>(x, w, bias, out, N, D, H, W, 0, zx.nth, zx.ntw,
+                                                                         zx.zsplit, bn, (uint16_t*)x_bf16);
+    else
+        c_to_one_zwalk12_k<8, true, false><<<(unsigned)zx.nb, 256, 0, s>>>(x, w, bias, out, N, D, H, W, 0, zx.nth, zx.ntw,
+                                                                          zx.zsplit, bn, nullptr);
     SIV_CHECK_LAUNCH("bnact_conv3d_k3_to1(fwd)");
     return SIV_OK;
 }
