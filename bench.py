@@ -328,7 +328,7 @@ def main():
     # weight gradients kept on the main stream, so that nothing shares the chip with them (inside the
     # timed region a side-stream weight gradient time-shares the CUs and the event pair would measure that).
     # Each entry carries the algorithmic bytes (every tensor once) and the bytes its passes really move.
-    hbm_events = {"bn_act_bwd": [], "stem_bn_bwd": [], "conv_64_to_1": []}
+    hbm_events = {"bn_act_bwd": [], "stem_bn_bwd": [], "stem_wgrad": [], "conv_64_to_1": []}
     hbm_on = {"on": False}
 
     def timed_hbm(orig, name, hit_fn, bytes_fn):
@@ -361,6 +361,13 @@ def main():
             lambda dout, x, w, bias, mean, var, gamma, beta, keep, *r: (
                 2 * dout.numel() * 4 + (dout.numel() if torch.is_tensor(keep) else 0),
                 3 * dout.numel() * 4 + (2 * dout.numel() if torch.is_tensor(keep) else 0)))
+        # the stem's backward where its input needs no gradient (the E-step's three encoder passes): weight,
+        # bias and BatchNorm-affine gradients from one pass over dout plus the decision bits of the forward pass
+        # (1/16 of dout's bytes) and two passes over the single-channel input; nothing written
+        B.conv1_bnact_wgrad = timed_hbm(
+            B.conv1_bnact_wgrad, "stem_wgrad",
+            lambda dout, *r: dout.shape[1] == 64 and tuple(dout.shape[2:]) == DIMS,
+            lambda dout, x, *r: (dout.numel() * 4 + dout.numel() // 4 + 2 * x.numel() * 4,) * 2)
         # (the output convolution applies the BatchNorm + LeakyReLU of the block in front while it loads:
         # the raw 64-channel tensor read once, one channel written; one pass)
         B.bnact_conv_to1_fwd = timed_hbm(

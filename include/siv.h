@@ -156,6 +156,37 @@ int siv_conv1_bnact_bwd(const float* dout, const float* x, const float* w, const
                         const uint64_t* mask_epoch, float p, float slope, float eps, float* dy, float* dgamma,
                         float* dbeta, int accumulate, int N, int D, int H, int W, int Cout,
                         void* ws, size_t ws_bytes, siv_stream_t stream);
+/* The same stem (models/models.py:91-96) with the dropout and activation decisions of the forward pass kept
+ * as two bits per output element, so that the backward passes neither redraw the mask nor read a mask
+ * tensor -- and, where the stem's input needs no gradient (it is the data or a detached reconstruction in
+ * utils/my_trainer.py:249, 266-267), so that the backward is ONE pass over dout:
+ * _fwd_bits = siv_conv1_bnact_fwd_bf16 (out_bf16 may be NULL) that also writes bits[_bits_bytes]: one byte
+ *   per channel quad q of a voxel (byte index = element index of out / 4), bit j = channel 4q + j was kept
+ *   by the dropout (all set without dropout), bit 4 + j = its BatchNorm output was > 0.
+ * _bwd_bits = siv_conv1_bnact_bwd with the mask taken from bits (bit-identical results).
+ * _wgrad_bits: dw[Cout][27], dbias[Cout] (of the convolution), dgamma, dbeta -- each optional, written or
+ *   (accumulate = 1) added -- straight from dout, x and bits.  The gradient dy of the convolution output is
+ *   never formed: with dz = dout * keep / (1 - p) * act'(z) and the input's own 28 x 28 tap correlation,
+ *   BatchNorm's backward and the weight gradient are linear maps of T[c][tap] = sum_v dz[v][c] x[v + tap]
+ *   (formulas at stem_autocorr_k in csrc/conv_thin.hip); sums over blocks and the combination in double
+ *   precision.  Equals siv_conv1_bnact_bwd followed by siv_conv3d_k3_wgrad up to fp32 rounding. */
+size_t siv_conv1_bnact_bits_bytes(int N, int D, int H, int W, int Cout);
+int siv_conv1_bnact_fwd_bits(const float* x, const float* w, const float* bias, const float* gamma,
+                             const float* beta, const uint8_t* keep, uint64_t mask_seed, uint64_t mask_stream_id,
+                             const uint64_t* mask_epoch, float p, float slope, float eps, int train,
+                             float* mean, float* var, float* running_mean, float* running_var,
+                             int64_t* num_batches_tracked, float momentum, float* out, void* out_bf16, void* bits,
+                             int N, int D, int H, int W, int Cout, void* ws, size_t ws_bytes, siv_stream_t stream);
+int siv_conv1_bnact_bwd_bits(const float* dout, const float* x, const float* w, const float* bias,
+                             const float* mean, const float* var, const float* gamma, const float* beta,
+                             const void* bits, float p, float slope, float eps, float* dy, float* dgamma,
+                             float* dbeta, int accumulate, int N, int D, int H, int W, int Cout,
+                             void* ws, size_t ws_bytes, siv_stream_t stream);
+int siv_conv1_bnact_wgrad_bits(const float* dout, const float* x, const float* w, const float* bias,
+                               const float* mean, const float* var, const float* gamma, const void* bits,
+                               float p, float slope, float eps, float* dw, float* dbias, float* dgamma,
+                               float* dbeta, int accumulate, int N, int D, int H, int W, int Cout,
+                               void* ws, size_t ws_bytes, siv_stream_t stream);
 
 /* BatchNorm3d + LeakyReLU folded into the Cin -> 1 convolution behind them: the decoder's last block
  * ends in conv -> BatchNorm -> LeakyReLU and feeds the output layer nn.Conv3d(in_ch, 1, 3, 1, 1)

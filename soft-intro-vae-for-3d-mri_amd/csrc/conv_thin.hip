@@ -399,10 +399,15 @@ __global__ __launch_bounds__(256, 3) void tail_bn_bwd_k(const float* __restrict_
 //   SM_BAPP:  dy = a * (dz - sum(dz)/M - xhat * sum(dz * xhat)/M)            (gradient of y, for the
 //             stem's weight gradient)
 // Recomputed values are bit-identical in every pass (same instruction sequence).
+// BITS: the forward pass also leaves two bits per output element -- kept by the dropout, z > 0 -- as one byte
+// per channel quad of a voxel (bits 0..3: kept, bits 4..7: positive; byte index = element index / 4), and the
+// backward passes take the dropout decision from there instead of a mask tensor or the generator.  (One
+// 32-bit word per lane and tile -- four voxels along x -- was measured too: one store instead of four, but
+// its index arithmetic costs the apply pass more than the stores do; 470 against 500 us.)
 // ---------------------------------------------------------------------------------
 enum { SM_STATS = 0, SM_APPLY = 1, SM_BSUM = 2, SM_BAPP = 3 };
 
-template <int MODE>
+template <int MODE, bool BITS = false>
 __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                                                     const float* __restrict__ w,
                                                     const float* __restrict__ bias, BnPrologue bn,
@@ -412,11 +417,13 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                                                     float* __restrict__ part, float* __restrict__ out,
                                                     int N, int D, int H, int W, int C, int nbd, int nbh,
                                                     int nbw, int bricks_per_block, int nbricks,
-                                                    uint16_t* __restrict__ out_bf16) {
+                                                    uint16_t* __restrict__ out_bf16,
+                                                    uint8_t* __restrict__ bits = nullptr) {
     // out_bf16 (SM_APPLY, optional): a bf16 copy of the output, written beside it
     __shared__ float hal[2][TH_V];
+    constexpr bool BITS_IN = BITS && (MODE == SM_BSUM || MODE == SM_BAPP);
     // dropout: a mask tensor (keep), or the mask drawn here from the element index (rk.on), or none
-    const bool masked = MODE != SM_STATS && (keep != nullptr || rk.on);
+    const bool masked = MODE != SM_STATS && (BITS_IN || keep != nullptr || rk.on);
     const uint64_t rsid = (rk.on && rk.epoch) ? rk.sid + *rk.epoch * SIV_EPOCH_STRIDE : rk.sid;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = lane & 15, kk = lane >> 4;
@@ -476,7 +483,8 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                 off[e] = ok[e] ? base + ((long)dyy * W + dx) * C : 0;
                 // what the pass reads goes out first (clamped, unconditional) and has the products to arrive
                 if (MODE == SM_BSUM || MODE == SM_BAPP) gv[e] = *reinterpret_cast<const float4*>(dout + off[e]);
-                if (MODE != SM_STATS && keep) kv[e] = *reinterpret_cast<const uint32_t*>(keep + off[e]);
+                if (BITS_IN) kv[e] = bits[off[e] >> 2];
+                else if (MODE != SM_STATS && keep) kv[e] = *reinterpret_cast<const uint32_t*>(keep + off[e]);
             }
             __builtin_amdgcn_sched_barrier(0);
             const float* hp = hal[buf] + (wv * TH_H + 2 * tl + (q >> 3)) * TH_W + (q & 7);
@@ -496,7 +504,11 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                 const float gg[4] = {gv[e].x, gv[e].y, gv[e].z, gv[e].w};
                 float o[4];
                 bool kp[4] = {true, true, true, true};
-                if (MODE != SM_STATS && keep) {
+                uint32_t pos = 0;
+                if (BITS_IN) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) kp[j] = ((kv[e] >> j) & 1u) != 0;
+                } else if (MODE != SM_STATS && keep) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) kp[j] = ((kv[e] >> (8 * j)) & 0xffu) != 0;
                 } else if (MODE != SM_STATS && rk.on) {
@@ -520,6 +532,7 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                         float r = z > 0.f ? z : z * bn.slope;
                         if (masked) r = kp[j] ? r * dscale : 0.f;
                         o[j] = r;
+                        if (BITS) pos |= (kp[j] ? 1u : 0u) << j | (z > 0.f ? 16u : 0u) << j;
                         continue;
                     }
                     float g = gg[j];
@@ -538,6 +551,7 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                 if ((MODE == SM_APPLY || MODE == SM_BAPP) && ok[e]) {
                     *reinterpret_cast<float4*>(out + off[e]) = make_float4(o[0], o[1], o[2], o[3]);
                     if (MODE == SM_APPLY && out_bf16) thin_st_bf4(out_bf16, off[e], make_float4(o[0], o[1], o[2], o[3]));
+                    if (MODE == SM_APPLY && BITS) bits[off[e] >> 2] = (uint8_t)pos;
                 }
             }
         }
@@ -1127,12 +1141,16 @@ __global__ __launch_bounds__(256) void thin_wg_k(const float* __restrict__ a,
 // one partial row per block is written, part[block][C][28], as above.
 // ---------------------------------------------------------------------------------
 // GBF: g points at the bf16 copy of the (raw) multi-channel operand.
-template <bool BN, bool GBF>
+// SB: g is the gradient behind the stem's Dropout and LeakyReLU; every element is first taken back through
+// them with the two bits the stem's forward pass left per element (stem_bn_k): g * keep / (1 - p) * act'(z).
+template <bool BN, bool GBF, bool SB = false>
 __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict__ a,
                                                       const float* __restrict__ g,
                                                       float* __restrict__ part, int N, int D, int H, int W,
                                                       int C, int nbd, int nbh, int nbw,
-                                                      int bricks_per_block, BnPrologue bn) {
+                                                      int bricks_per_block, BnPrologue bn,
+                                                      const uint8_t* __restrict__ sbits = nullptr,
+                                                      float dscale = 1.f) {
     __shared__ float hal[2][TH_V];
     __shared__ float red[64 * 28];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1181,21 +1199,24 @@ __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict
         const long gbase = ((((long)n * D + gz) * H + y0) * W + x0) * C + 4 * q;
         const float* hp = hal[buf] + wv * TH_H * TH_W + kk;
         // group u (0..15): brick row u >> 1, voxels 4 (u & 1) + kk
-        auto load4 = [&](float4 (&dst)[4], int c4) {
+        auto load4 = [&](float4 (&dst)[4], uint32_t (&bd)[4], int c4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int dy = 2 * c4 + (u >> 1), dx = 4 * (u & 1) + kk;
                 const bool ok = qok && y0 + dy < H && x0 + dx < W;
                 // masked lanes read the start of the tensor (no branch around the load) and are
                 // zeroed where the value is used, so nothing waits for the load here
-                dst[u] = thin_ld4<GBF>(g, ok ? gbase + (long)(dy * W + dx) * C : 0);
+                const long e = ok ? gbase + (long)(dy * W + dx) * C : 0;
+                dst[u] = thin_ld4<GBF>(g, e);
+                if (SB) bd[u] = sbits[e >> 2];              // the decision byte of (this voxel, channel quad q)
             }
         };
         float4 av[2][4];
-        load4(av[0], 0);
+        uint32_t ab[2][4];
+        load4(av[0], ab[0], 0);
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
-            if (c4 < 3) load4(av[(c4 + 1) & 1], c4 + 1);
+            if (c4 < 3) load4(av[(c4 + 1) & 1], ab[(c4 + 1) & 1], c4 + 1);
             __builtin_amdgcn_sched_barrier(0);          // keep the loads ahead of the products
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1209,6 +1230,14 @@ __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict
                 if (BN)
                     v = make_float4(bn_act1(v.x, ca.x, cb.x, bn.slope), bn_act1(v.y, ca.y, cb.y, bn.slope),
                                     bn_act1(v.z, ca.z, cb.z, bn.slope), bn_act1(v.w, ca.w, cb.w, bn.slope));
+                if (SB) {
+                    // the order of stem_bn_k's backward passes: mask and scale, then the slope
+                    const uint32_t b = ab[c4 & 1][u];
+                    v.x = ((b & 1u) ? v.x * dscale : 0.f) * ((b & 16u) ? 1.f : bn.slope);
+                    v.y = ((b & 2u) ? v.y * dscale : 0.f) * ((b & 32u) ? 1.f : bn.slope);
+                    v.z = ((b & 4u) ? v.z * dscale : 0.f) * ((b & 64u) ? 1.f : bn.slope);
+                    v.w = ((b & 8u) ? v.w * dscale : 0.f) * ((b & 128u) ? 1.f : bn.slope);
+                }
                 v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 #pragma unroll
                 for (int cg = 0; cg < 2; ++cg) {
@@ -1264,6 +1293,137 @@ __global__ __launch_bounds__(256) void thin_wg_reduce(const float* __restrict__ 
     if (t < 27) dst = mode == 0 ? dw + c * 27 + t : dw + (26 - t) * C + c;
     else if (mode == 0 && dbias) dst = dbias + c;
     if (dst) *dst = accumulate ? *dst + (float)s : (float)s;
+}
+
+// ---------------------------------------------------------------------------------
+// Weight-only backward of the encoder stem (Conv3d(1, C, 3) -> BatchNorm -> LeakyReLU -> Dropout) without
+// the gradient of the convolution output ever being formed.  With dz = dout * keep / (1 - p) * act'(z),
+// p[v][t] = a[v + tap t - 1] (zero padded), y = w p + bias, xhat = (y - mean) * inv, BatchNorm's backward is
+//   dy = ca * (dz - S / M - xhat * Q / M),   S = sum_v dz,   Q = sum_v dz * xhat,
+// and the convolution's weight gradient sum_v dy[v][c] p[v][t] is linear in it, so per channel c
+//   T[c][t]  = sum_v dz[v][c] p[v][t]                 (one pass over dout: thin_wg_mfma_k<.., SB>)
+//   Q        = inv * (sum_t w[c][t] T[c][t] + (bias - mean) S)
+//   X[c][t]  = sum_v xhat[v][c] p[v][t] = inv * (sum_t' w[c][t'] R[t'][t] + (bias - mean) A[t])
+//   dW[c][t] = ca * (T[c][t] - S / M * A[t] - Q / M * X[c][t])
+// where R[t'][t] = sum_v p[v][t'] p[v][t] and A[t] = sum_v p[v][t] depend on the single-channel input alone
+// (stem_autocorr_k: P^T P with a column of ones appended, 28 x 28, on the matrix pipe).  The sums over the
+// per-block partials and the combination run in double precision.
+// ---------------------------------------------------------------------------------
+typedef float f32x16t __attribute__((ext_vector_type(16)));
+
+// part[block][32][32] = sum over the block's bricks of P'^T P', P'[v] = (27 taps of the halo, 1, 0, 0, 0, 0).
+// Wave wv owns plane wv of every brick; one 32x32x2 instruction takes two voxels, both operands are the same
+// register (lane = (column, voxel)).
+__global__ __launch_bounds__(256, 3) void stem_autocorr_k(const float* __restrict__ a, float* __restrict__ part,
+                                                          int N, int D, int H, int W, int nbd, int nbh, int nbw,
+                                                          int bricks_per_block) {
+    __shared__ float hal[2][TH_V];
+    __shared__ float red[1024];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int t = lane & 31, k = lane >> 5;
+    const int toff = t < 27 ? ((t / 9) * TH_H + (t / 3) % 3) * TH_W + t % 3 : 0;
+    const float cst = t == 27 ? 1.f : 0.f;
+    f32x16t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const long nbricks = (long)N * nbd * nbh * nbw;
+    const long b0 = (long)blockIdx.x * bricks_per_block;
+    long b1 = b0 + bricks_per_block;
+    if (b1 > nbricks) b1 = nbricks;
+    int buf = 0;
+    float hr[TH_PER_THREAD];
+    if (b0 < b1) halo1_fetch(a, hr, (int)b0, nbd, nbh, nbw, D, H, W);
+    for (long br = b0; br < b1; ++br, buf ^= 1) {
+        int n, z0, y0, x0;
+        brick_coords((int)br, nbd, nbh, nbw, n, z0, y0, x0);
+        halo1_put(hal[buf], hr);
+        __syncthreads();
+        if (br + 1 < b1) halo1_fetch(a, hr, (int)br + 1, nbd, nbh, nbw, D, H, W);
+        __builtin_amdgcn_sched_barrier(0);
+        if (z0 + wv >= D) continue;
+        const float* hp = hal[buf] + wv * TH_H * TH_W + toff;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {                  // voxels 2 i + k of the plane: row i >> 2, x 2 (i & 3) + k
+            const int dy = i >> 2, dx = 2 * (i & 3) + k;
+            const bool ok = y0 + dy < H && x0 + dx < W;
+            float v = t < 27 ? hp[dy * TH_W + dx] : cst;
+            v = ok ? v : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, v, acc, 0, 0, 0);
+        }
+    }
+    // the four waves in fixed order; register r of lane (t, k) is row (r & 3) + 8 (r >> 2) + 4 k, column t
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wv == w) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * k;
+                red[row * 32 + t] = w == 0 ? acc[r] : red[row * 32 + t] + acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    float* pp = part + (long)blockIdx.x * 1024;
+    for (int idx = threadIdx.x; idx < 1024; idx += 256) pp[idx] = red[idx];
+}
+
+// Td[i] = sum_b tpart[b][i] (i < C * 28), Rd[i] = sum_b rpart[b][i] (i < 1024): one wave per element, double
+__global__ __launch_bounds__(256) void stem_wg_reduce_k(const float* __restrict__ tpart, int nblk_t, int nt,
+                                                        const float* __restrict__ rpart, int nblk_r,
+                                                        double* __restrict__ Td, double* __restrict__ Rd) {
+    const int lane = threadIdx.x & 63;
+    int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const float* src = tpart;
+    int nblk = nblk_t, n = nt;
+    double* dst = Td;
+    if (i >= nt) {
+        i -= nt;
+        src = rpart; nblk = nblk_r; n = 1024; dst = Rd;
+        if (i >= 1024) return;
+    }
+    double s = 0.0;
+    for (int b = lane; b < nblk; b += 64) s += (double)src[(long)b * n + i];
+    s = wave_sum_d(s);
+    if (lane == 0) dst[i] = s;
+}
+
+// one wave per channel: lanes 0..26 the taps, lane 27 the bias and the affine gradients
+__global__ __launch_bounds__(64) void stem_wg_final_k(const double* __restrict__ Td, const double* __restrict__ Rd,
+                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const float* __restrict__ mean, const float* __restrict__ var,
+                                                      const float* __restrict__ gamma, float eps, double M,
+                                                      float* __restrict__ dw, float* __restrict__ dbias,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      int accumulate) {
+    const int c = blockIdx.x, t = threadIdx.x;
+    if (t > 27) return;
+    // the constants of the kernels that apply this BatchNorm (fp32, their association)
+    const double inv = (double)(1.0f / sqrtf(var[c] + eps));
+    const double ca = (double)(gamma[c] / sqrtf(var[c] + eps));
+    const double bm = (double)(bias ? bias[c] : 0.f) - (double)mean[c];
+    const double* T = Td + c * 28;
+    const double S = T[27];
+    double wT = 0.0;
+    for (int u = 0; u < 27; ++u) wT += (double)w[c * 27 + u] * T[u];
+    const double Q = inv * (wT + bm * S);
+    const double k1 = S / M, k2 = Q / M;
+    if (t < 27) {
+        double wR = 0.0;
+        for (int u = 0; u < 27; ++u) wR += (double)w[c * 27 + u] * Rd[u * 32 + t];
+        const double At = Rd[27 * 32 + t];
+        const double X = inv * (wR + bm * At);
+        const float r = (float)(ca * (T[t] - k1 * At - k2 * X));
+        if (dw) dw[c * 27 + t] = accumulate ? dw[c * 27 + t] + r : r;
+    } else {
+        double wA = 0.0;
+        for (int u = 0; u < 27; ++u) wA += (double)w[c * 27 + u] * Rd[27 * 32 + u];
+        const double sx = inv * (wA + bm * M);                  // sum of xhat: zero up to the rounding of the mean
+        const float r = (float)(ca * (S - k1 * M - k2 * sx));
+        if (dbias) dbias[c] = accumulate ? dbias[c] + r : r;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)Q : (float)Q;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)S : (float)S;
+    }
 }
 
 // sum of a flat array (gradient of the single-channel bias), two deterministic stages
@@ -1431,7 +1591,7 @@ int stem_bnact_fwd_launch(const float* x, const float* w, const float* bias, con
                           const uint8_t* keep, const PhiloxMask& rk, float p, float slope, float eps, int train,
                           float* mean, float* var, float* running_mean, float* running_var, int64_t* nbt,
                           float momentum, float* out, int N, int D, int H, int W, int C, void* ws, size_t ws_bytes,
-                          hipStream_t s, void* out_bf16) {
+                          hipStream_t s, void* out_bf16, void* bits) {
     StemGrid g;
     int rc = stem_grid("conv1_bnact_fwd", N, D, H, W, C, ws_bytes, g);
     if (rc) return rc;
@@ -1446,9 +1606,14 @@ int stem_bnact_fwd_launch(const float* x, const float* w, const float* bias, con
                                 nbt, momentum, s);
         if (rc) return rc;
     }
-    stem_bn_k<SM_APPLY><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, nullptr, nullptr, 0.f, nullptr, out, N,
-                                                        D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks,
-                                                        (uint16_t*)out_bf16);
+    if (bits)
+        stem_bn_k<SM_APPLY, true><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, nullptr, nullptr, 0.f, nullptr,
+                                                                  out, N, D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb,
+                                                                  (int)g.nbricks, (uint16_t*)out_bf16, (uint8_t*)bits);
+    else
+        stem_bn_k<SM_APPLY><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, nullptr, nullptr, 0.f, nullptr, out, N,
+                                                            D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks,
+                                                            (uint16_t*)out_bf16);
     SIV_CHECK_LAUNCH("conv1_bnact_fwd(apply)");
     return SIV_OK;
 }
@@ -1458,7 +1623,7 @@ int stem_bnact_bwd_launch(const float* dout, const float* x, const float* w, con
                           const float* var, const float* gamma, const float* beta, const uint8_t* keep,
                           const PhiloxMask& rk, float p, float slope, float eps, float* dy, float* dgamma,
                           float* dbeta, int accumulate, int N, int D, int H, int W, int C, void* ws, size_t ws_bytes,
-                          hipStream_t s) {
+                          hipStream_t s, const void* bits) {
     StemGrid g;
     int rc = stem_grid("conv1_bnact_bwd", N, D, H, W, C, ws_bytes, g);
     if (rc) return rc;
@@ -1466,14 +1631,68 @@ int stem_bnact_bwd_launch(const float* dout, const float* x, const float* w, con
     float* part = (float*)ws;
     float* sums = (float*)((char*)ws + g.part_bytes);
     const float invM = 1.0f / (float)((long)N * D * H * W);
-    stem_bn_k<SM_BSUM><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, dout, nullptr, invM, part, nullptr, N, D,
-                                                       H, W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks, nullptr);
+    uint8_t* bt = (uint8_t*)bits;           // read only by the backward instantiations
+    if (bt)
+        stem_bn_k<SM_BSUM, true><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, nullptr, PhiloxMask{}, p, dout, nullptr, invM,
+                                                                 part, nullptr, N, D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb,
+                                                                 (int)g.nbricks, nullptr, bt);
+    else
+        stem_bn_k<SM_BSUM><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, dout, nullptr, invM, part, nullptr, N,
+                                                           D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks, nullptr);
     SIV_CHECK_LAUNCH("conv1_bnact_bwd(sums)");
     rc = bn_bwd_finalize_launch(part, (int)g.nblk, C, sums, dgamma, dbeta, accumulate, s);
     if (rc) return rc;
-    stem_bn_k<SM_BAPP><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, dout, sums, invM, nullptr, dy, N, D, H,
-                                                       W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks, nullptr);
+    if (bt)
+        stem_bn_k<SM_BAPP, true><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, nullptr, PhiloxMask{}, p, dout, sums, invM,
+                                                                 nullptr, dy, N, D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb,
+                                                                 (int)g.nbricks, nullptr, bt);
+    else
+        stem_bn_k<SM_BAPP><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, dout, sums, invM, nullptr, dy, N, D, H,
+                                                           W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks, nullptr);
     SIV_CHECK_LAUNCH("conv1_bnact_bwd(apply)");
+    return SIV_OK;
+}
+
+// Weight-only backward of the same (dw, dbias of the convolution, dgamma, dbeta) from the gradient behind the
+// dropout and the bits of the forward pass: one pass over dout, one over the single-channel input; the
+// gradient of the convolution output is never formed (algebra at stem_autocorr_k).
+int stem_bnact_wgrad_launch(const float* dout, const float* x, const float* w, const float* bias, const float* mean,
+                            const float* var, const float* gamma, const void* bits, float p, float slope, float eps,
+                            float* dw, float* dbias, float* dgamma, float* dbeta, int accumulate, int N, int D,
+                            int H, int W, int C, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (C % 4 != 0 || C > 64) {
+        set_error("conv1_bnact_wgrad: needs Cout %% 4 == 0 and Cout <= 64 (got %d)", C);
+        return SIV_EINVAL;
+    }
+    const int nbd = (D + TB_D - 1) / TB_D, nbh = (H + TB_H - 1) / TB_H, nbw = (W + TB_W - 1) / TB_W;
+    const long nbricks = (long)N * nbd * nbh * nbw;
+    if (nbricks > 0x7fffffffL || (long)N * D * H * W * C > 0x7fffffffffL) {
+        set_error("conv1_bnact_wgrad: volume too large");
+        return SIV_EINVAL;
+    }
+    long nblk = nbricks < 4 * THIN_CUS ? nbricks : 4 * THIN_CUS;      // one round of four blocks per CU
+    const int bpb = (int)cdiv(nbricks, nblk);
+    nblk = cdiv(nbricks, bpb);
+    const size_t tpart_bytes = align256((size_t)nblk * C * 28 * sizeof(float));
+    const size_t rpart_bytes = align256((size_t)nblk * 1024 * sizeof(float));
+    const size_t td_bytes = align256((size_t)C * 28 * sizeof(double));
+    SIV_CHECK_WS(tpart_bytes + rpart_bytes + td_bytes + 1024 * sizeof(double), ws_bytes, "conv1_bnact_wgrad");
+    float* tpart = (float*)ws;
+    float* rpart = (float*)((char*)ws + tpart_bytes);
+    double* Td = (double*)((char*)ws + tpart_bytes + rpart_bytes);
+    double* Rd = (double*)((char*)ws + tpart_bytes + rpart_bytes + td_bytes);
+    BnPrologue bn{};
+    bn.slope = slope;
+    thin_wg_mfma_k<false, false, true><<<(unsigned)nblk, 256, 0, s>>>(x, dout, tpart, N, D, H, W, C, nbd, nbh, nbw, bpb, bn,
+                                                                     (const uint8_t*)bits, 1.0f / (1.0f - p));
+    SIV_CHECK_LAUNCH("conv1_bnact_wgrad(gradient pass)");
+    stem_autocorr_k<<<(unsigned)nblk, 256, 0, s>>>(x, rpart, N, D, H, W, nbd, nbh, nbw, bpb);
+    SIV_CHECK_LAUNCH("conv1_bnact_wgrad(input pass)");
+    stem_wg_reduce_k<<<(C * 28 + 1024 + 3) / 4, 256, 0, s>>>(tpart, (int)nblk, C * 28, rpart, (int)nblk, Td, Rd);
+    SIV_CHECK_LAUNCH("conv1_bnact_wgrad(reduce)");
+    stem_wg_final_k<<<C, 64, 0, s>>>(Td, Rd, w, bias, mean, var, gamma, eps, (double)((long)N * D * H * W), dw, dbias,
+                                     dgamma, dbeta, accumulate);
+    SIV_CHECK_LAUNCH("conv1_bnact_wgrad(final)");
     return SIV_OK;
 }
 

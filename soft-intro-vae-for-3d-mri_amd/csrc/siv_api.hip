@@ -173,12 +173,16 @@ int stem_bnact_fwd_launch(const float* x, const float* w, const float* bias, con
                           const uint8_t* keep, const PhiloxMask& rk, float p, float slope, float eps, int train,
                           float* mean, float* var, float* running_mean, float* running_var, int64_t* nbt,
                           float momentum, float* out, int N, int D, int H, int W, int C, void* ws, size_t ws_bytes,
-                          hipStream_t s, void* out_bf16 = nullptr);
+                          hipStream_t s, void* out_bf16 = nullptr, void* bits = nullptr);
+int stem_bnact_wgrad_launch(const float* dout, const float* x, const float* w, const float* bias, const float* mean,
+                            const float* var, const float* gamma, const void* bits, float p, float slope, float eps,
+                            float* dw, float* dbias, float* dgamma, float* dbeta, int accumulate, int N, int D,
+                            int H, int W, int C, void* ws, size_t ws_bytes, hipStream_t s);
 int stem_bnact_bwd_launch(const float* dout, const float* x, const float* w, const float* bias, const float* mean,
                           const float* var, const float* gamma, const float* beta, const uint8_t* keep,
                           const PhiloxMask& rk, float p, float slope, float eps, float* dy, float* dgamma,
                           float* dbeta, int accumulate, int N, int D, int H, int W, int C, void* ws, size_t ws_bytes,
-                          hipStream_t s);
+                          hipStream_t s, const void* bits = nullptr);
 bool k3_thin_bn_fwd_supported(int N, int D, int H, int W, int Cin);
 int k3_thin_bn_fwd_launch(const float* x, const BnPrologue& bn, const float* w, const float* bias, float* out,
                           int N, int D, int H, int W, int Cin, hipStream_t s, void* x_bf16 = nullptr);
@@ -414,6 +418,13 @@ extern "C" int siv_conv3d_k3_fwd_bnstats(const float* x, const float* w, const f
 extern "C" int siv_conv1_bnact_supported(int Cout) {
     return conv_path() != 1 && Cout % 4 == 0 && Cout >= 4 && Cout <= 64 ? 1 : 0;
 }
+extern "C" int siv_conv1_bnact_fwd_bits(const float* x, const float* w, const float* bias, const float* gamma,
+                                        const float* beta, const uint8_t* keep, uint64_t mask_seed,
+                                        uint64_t mask_stream_id, const uint64_t* mask_epoch, float p, float slope,
+                                        float eps, int train, float* mean, float* var, float* running_mean,
+                                        float* running_var, int64_t* num_batches_tracked, float momentum,
+                                        float* out, void* out_bf16, void* bits, int N, int D, int H, int W, int Cout,
+                                        void* ws, size_t ws_bytes, siv_stream_t stream);
 extern "C" int siv_conv1_bnact_fwd_bf16(const float* x, const float* w, const float* bias, const float* gamma,
                                         const float* beta, const uint8_t* keep, uint64_t mask_seed,
                                         uint64_t mask_stream_id, const uint64_t* mask_epoch, float p, float slope,
@@ -439,6 +450,20 @@ extern "C" int siv_conv1_bnact_fwd_bf16(const float* x, const float* w, const fl
                                         float* running_var, int64_t* num_batches_tracked, float momentum,
                                         float* out, void* out_bf16, int N, int D, int H, int W, int Cout, void* ws,
                                         size_t ws_bytes, siv_stream_t stream) {
+    return siv_conv1_bnact_fwd_bits(x, w, bias, gamma, beta, keep, mask_seed, mask_stream_id, mask_epoch, p, slope, eps,
+                                    train, mean, var, running_mean, running_var, num_batches_tracked, momentum, out,
+                                    out_bf16, nullptr, N, D, H, W, Cout, ws, ws_bytes, stream);
+}
+extern "C" size_t siv_conv1_bnact_bits_bytes(int N, int D, int H, int W, int Cout) {
+    return (size_t)N * D * H * W * (size_t)(Cout / 4);
+}
+extern "C" int siv_conv1_bnact_fwd_bits(const float* x, const float* w, const float* bias, const float* gamma,
+                                        const float* beta, const uint8_t* keep, uint64_t mask_seed,
+                                        uint64_t mask_stream_id, const uint64_t* mask_epoch, float p, float slope,
+                                        float eps, int train, float* mean, float* var, float* running_mean,
+                                        float* running_var, int64_t* num_batches_tracked, float momentum,
+                                        float* out, void* out_bf16, void* bits, int N, int D, int H, int W, int Cout,
+                                        void* ws, size_t ws_bytes, siv_stream_t stream) {
     SIV_CHECK_ARG(((uintptr_t)out_bf16 & 7) == 0, "conv1_bnact_fwd: the bf16 copy must be 8-byte aligned");
     SIV_CHECK_ARG(x && w && gamma && beta && mean && var && out, "conv1_bnact_fwd: null pointer");
     int rc = check_conv_shape("conv1_bnact_fwd", N, D, H, W, 1, Cout, 1);
@@ -453,7 +478,7 @@ extern "C" int siv_conv1_bnact_fwd_bf16(const float* x, const float* w, const fl
     const PhiloxMask rk{mask_seed, mask_stream_id, (const unsigned long long*)mask_epoch, keep == nullptr && p > 0.f};
     return stem_bnact_fwd_launch(x, w, bias, gamma, beta, keep, rk, p, slope, eps, train, mean, var, running_mean,
                                  running_var, num_batches_tracked, momentum, out, N, D, H, W, Cout, ws, ws_bytes,
-                                 (hipStream_t)stream, out_bf16);
+                                 (hipStream_t)stream, out_bf16, bits);
 }
 extern "C" int siv_conv1_bnact_bwd(const float* dout, const float* x, const float* w, const float* bias,
                                    const float* mean, const float* var, const float* gamma, const float* beta,
@@ -472,6 +497,38 @@ extern "C" int siv_conv1_bnact_bwd(const float* dout, const float* x, const floa
     const PhiloxMask rk{mask_seed, mask_stream_id, (const unsigned long long*)mask_epoch, keep == nullptr && p > 0.f};
     return stem_bnact_bwd_launch(dout, x, w, bias, mean, var, gamma, beta, keep, rk, p, slope, eps, dy, dgamma, dbeta,
                                  accumulate, N, D, H, W, Cout, ws, ws_bytes, (hipStream_t)stream);
+}
+extern "C" int siv_conv1_bnact_bwd_bits(const float* dout, const float* x, const float* w, const float* bias,
+                                        const float* mean, const float* var, const float* gamma, const float* beta,
+                                        const void* bits, float p, float slope, float eps, float* dy, float* dgamma,
+                                        float* dbeta, int accumulate, int N, int D, int H, int W, int Cout, void* ws,
+                                        size_t ws_bytes, siv_stream_t stream) {
+    SIV_CHECK_ARG(dout && x && w && mean && var && gamma && beta && dy && bits, "conv1_bnact_bwd_bits: null pointer");
+    int rc = check_conv_shape("conv1_bnact_bwd_bits", N, D, H, W, 1, Cout, 1);
+    if (rc) return rc;
+    SIV_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr),
+                  "conv1_bnact_bwd_bits: dgamma and dbeta must both be given or both be NULL");
+    SIV_CHECK_ARG(p >= 0.f && p < 1.f, "conv1_bnact_bwd_bits: dropout probability %g outside [0, 1)", (double)p);
+    SIV_CHECK_ARG(aligned16(dout) && aligned16(dy) && aligned16(ws),
+                  "conv1_bnact_bwd_bits: dout, dy and the workspace must be 16-byte aligned");
+    SIV_PICK("thin");
+    return stem_bnact_bwd_launch(dout, x, w, bias, mean, var, gamma, beta, nullptr, PhiloxMask{}, p, slope, eps, dy,
+                                 dgamma, dbeta, accumulate, N, D, H, W, Cout, ws, ws_bytes, (hipStream_t)stream, bits);
+}
+extern "C" int siv_conv1_bnact_wgrad_bits(const float* dout, const float* x, const float* w, const float* bias,
+                                          const float* mean, const float* var, const float* gamma, const void* bits,
+                                          float p, float slope, float eps, float* dw, float* dbias, float* dgamma,
+                                          float* dbeta, int accumulate, int N, int D, int H, int W, int Cout,
+                                          void* ws, size_t ws_bytes, siv_stream_t stream) {
+    SIV_CHECK_ARG(dout && x && w && mean && var && gamma && bits, "conv1_bnact_wgrad_bits: null pointer");
+    SIV_CHECK_ARG(dw || dbias || dgamma || dbeta, "conv1_bnact_wgrad_bits: no output requested");
+    int rc = check_conv_shape("conv1_bnact_wgrad_bits", N, D, H, W, 1, Cout, 1);
+    if (rc) return rc;
+    SIV_CHECK_ARG(p >= 0.f && p < 1.f, "conv1_bnact_wgrad_bits: dropout probability %g outside [0, 1)", (double)p);
+    SIV_CHECK_ARG(aligned16(dout) && aligned16(ws), "conv1_bnact_wgrad_bits: dout and the workspace must be 16-byte aligned");
+    SIV_PICK("thin");
+    return stem_bnact_wgrad_launch(dout, x, w, bias, mean, var, gamma, bits, p, slope, eps, dw, dbias, dgamma, dbeta,
+                                   accumulate, N, D, H, W, Cout, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // BatchNorm + LeakyReLU of the layer in front folded into a Cin -> 1 convolution (the decoder's output layer

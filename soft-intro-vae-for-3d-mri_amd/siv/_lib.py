@@ -34,6 +34,12 @@ SIGNATURES = {
                             _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_conv1_bnact_fwd_bf16": [_f, _f, _f, _f, _f, _f, _u64, _u64, _f, _fl, _fl, _fl, _i, _f, _f, _f, _f, _f, _fl, _f,
                                  _f, _i, _i, _i, _i, _i, _f, _sz, _f],
+    "siv_conv1_bnact_fwd_bits": [_f, _f, _f, _f, _f, _f, _u64, _u64, _f, _fl, _fl, _fl, _i, _f, _f, _f, _f, _f, _fl, _f,
+                                 _f, _f, _i, _i, _i, _i, _i, _f, _sz, _f],
+    "siv_conv1_bnact_bwd_bits": [_f, _f, _f, _f, _f, _f, _f, _f, _f, _fl, _fl, _fl, _f, _f, _f, _i,
+                                 _i, _i, _i, _i, _i, _f, _sz, _f],
+    "siv_conv1_bnact_wgrad_bits": [_f, _f, _f, _f, _f, _f, _f, _f, _fl, _fl, _fl, _f, _f, _f, _f, _i,
+                                   _i, _i, _i, _i, _i, _f, _sz, _f],
     "siv_bnact_conv3d_k3_to1_fwd_bf16": [_f, _f, _f, _f, _f, _fl, _fl, _f, _f, _f, _f, _i, _i, _i, _i, _i, _f],
     "siv_bnact_conv3d_k3_to1_dgrad_bf16": [_f, _f, _f, _f, _f, _f, _f, _fl, _fl, _f, _f, _f, _i, _i, _i, _i, _i, _i, _f,
                                            _sz, _f],
@@ -122,6 +128,8 @@ def load() -> C.CDLL:
     lib.siv_version.restype = C.c_int
     lib.siv_version.argtypes = []
     lib.siv_workspace_bytes.restype = C.c_size_t
+    lib.siv_conv1_bnact_bits_bytes.restype = C.c_size_t
+    lib.siv_conv1_bnact_bits_bytes.argtypes = [_i] * 5
     lib.siv_workspace_bytes.argtypes = []
     _lib = lib
     return lib

@@ -238,10 +238,14 @@ class HipBackend:
         m = 2 ** 64 - 1
         return None, (keep.seed & m, keep.stream_id & m, keep.epoch)
 
+    stem_bits = True        # conv1_bnact_fwd(emit_bits=True), conv1_bnact_bwd(bits=...), conv1_bnact_wgrad exist
+
     def conv1_bnact_fwd(self, x, w, bias, gamma, beta, keep, p, slope, eps, train: bool, running_mean,
-                        running_var, nbt, momentum: float, emit_bf16: bool = False):
+                        running_var, nbt, momentum: float, emit_bf16: bool = False, emit_bits: bool = False):
         """Returns (out, mean, var); in evaluation mode mean / var are the running statistics.  ``emit_bf16``:
-        (out, mean, var, bf16 copy of out), the copy written by the same pass."""
+        (out, mean, var, bf16 copy of out), the copy written by the same pass.  ``emit_bits``: one more
+        element, the uint8 tensor with the dropout / activation decisions of the pass (two bits per output
+        element) that ``conv1_bnact_bwd(bits=...)`` and ``conv1_bnact_wgrad`` take."""
         masked = keep is not None       # the C entry point reads "no mask tensor, p > 0" as "draw the mask"
         keep, mk = self._mask_args(keep)
         self._check_dev(x, w, bias, gamma, beta, keep, mk[2], running_mean, running_var, nbt)
@@ -257,19 +261,23 @@ class HipBackend:
             mean, var, rm, rv, nb = running_mean, running_var, None, None, None
         ws, wsb = self._workspace(x)
         oh = torch.empty_like(out, dtype=torch.bfloat16) if emit_bf16 else None
-        _lib.check(self.lib.siv_conv1_bnact_fwd_bf16(_p(x), _p(w), _p(bias), _p(gamma), _p(beta), _p(keep), mk[0],
+        bits = (torch.empty(self.lib.siv_conv1_bnact_bits_bytes(N, D, H, W, C), dtype=torch.uint8, device=x.device)
+                if emit_bits else None)
+        _lib.check(self.lib.siv_conv1_bnact_fwd_bits(_p(x), _p(w), _p(bias), _p(gamma), _p(beta), _p(keep), mk[0],
                                                      mk[1], _p(mk[2]), float(p) if masked else 0.0, float(slope),
                                                      float(eps), int(train), _p(mean), _p(var), _p(rm),
-                                                     _p(rv), _p(nb), float(momentum), _p(out), _p(oh), N, D, H, W, C,
-                                                     ws, wsb, self._stream(x)), "siv_conv1_bnact_fwd")
-        return (out, mean, var, oh) if emit_bf16 else (out, mean, var)
+                                                     _p(rv), _p(nb), float(momentum), _p(out), _p(oh), _p(bits),
+                                                     N, D, H, W, C, ws, wsb, self._stream(x)), "siv_conv1_bnact_fwd")
+        res = (out, mean, var, oh) if emit_bf16 else (out, mean, var)
+        return res + (bits,) if emit_bits else res
 
     def conv1_bnact_bwd(self, dout, x, w, bias, mean, var, gamma, beta, keep, p, slope, eps,
-                        want_affine: bool, dgamma_out=None, dbeta_out=None):
-        """Gradient of the convolution output (and of gamma / beta: returned, or ADDED into the buffers)."""
+                        want_affine: bool, dgamma_out=None, dbeta_out=None, bits=None):
+        """Gradient of the convolution output (and of gamma / beta: returned, or ADDED into the buffers).
+        ``bits`` (from the forward pass) replaces ``keep``; ``p`` is then the dropout probability of that pass."""
         masked = keep is not None
         keep, mk = self._mask_args(keep)
-        self._check_dev(dout, x, w, bias, mean, var, gamma, beta, keep, mk[2], dgamma_out, dbeta_out)
+        self._check_dev(dout, x, w, bias, mean, var, gamma, beta, keep, mk[2], dgamma_out, dbeta_out, bits)
         dout, x, w = cl(dout), x.contiguous(), cl(w)
         N, C, D, H, W = dout.shape
         dy = like(dout)
@@ -281,12 +289,45 @@ class HipBackend:
             dgamma = torch.empty(C, device=x.device, dtype=torch.float32) if want_affine else None
             dbeta = torch.empty(C, device=x.device, dtype=torch.float32) if want_affine else None
         ws, wsb = self._workspace(dout)
+        if bits is not None:
+            _lib.check(self.lib.siv_conv1_bnact_bwd_bits(_p(dout), _p(x), _p(w), _p(bias), _p(mean), _p(var),
+                                                         _p(gamma), _p(beta), _p(bits), float(p), float(slope),
+                                                         float(eps), _p(dy), _p(dgamma), _p(dbeta), acc, N, D, H, W,
+                                                         C, ws, wsb, self._stream(dout)), "siv_conv1_bnact_bwd_bits")
+            return dy, dgamma, dbeta
         _lib.check(self.lib.siv_conv1_bnact_bwd(_p(dout), _p(x), _p(w), _p(bias), _p(mean), _p(var), _p(gamma),
                                                 _p(beta), _p(keep), mk[0], mk[1], _p(mk[2]),
                                                 float(p) if masked else 0.0, float(slope), float(eps), _p(dy),
                                                 _p(dgamma), _p(dbeta), acc, N, D, H, W, C, ws, wsb,
                                                 self._stream(dout)), "siv_conv1_bnact_bwd")
         return dy, dgamma, dbeta
+
+    def conv1_bnact_wgrad(self, dout, x, w, bias, mean, var, gamma, bits, p, slope, eps,
+                          dw_out=None, dbias_out=None, dgamma_out=None, dbeta_out=None, want_bias: bool = True,
+                          want_affine: bool = True):
+        """Weight-only backward of the stem: (dw, dbias, dgamma, dbeta) straight from ``dout``, the input and
+        the bits of the forward pass, without the gradient of the convolution output.  Either all four ``*_out``
+        buffers are given (the results are ADDED into them) or none (fresh tensors are returned; ``None`` for
+        what was not asked for)."""
+        self._check_dev(dout, x, w, bias, mean, var, gamma, bits, dw_out, dbias_out, dgamma_out, dbeta_out)
+        dout, x, w = cl(dout), x.contiguous(), cl(w)
+        N, C, D, H, W = dout.shape
+        want_bias = want_bias and bias is not None
+        if dw_out is not None:
+            assert dw_out.is_contiguous(memory_format=torch.channels_last_3d) or dw_out.is_contiguous()
+            dw, db, dg, dbt, acc = dw_out, dbias_out if want_bias else None, dgamma_out, dbeta_out, 1
+        else:
+            dw = torch.empty_like(w)
+            new = lambda: torch.empty(C, device=x.device, dtype=torch.float32)
+            db = new() if want_bias else None
+            dg, dbt = (new(), new()) if want_affine else (None, None)
+            acc = 0
+        ws, wsb = self._workspace(dout)
+        _lib.check(self.lib.siv_conv1_bnact_wgrad_bits(_p(dout), _p(x), _p(w), _p(bias), _p(mean), _p(var), _p(gamma),
+                                                       _p(bits), float(p), float(slope), float(eps), _p(dw), _p(db),
+                                                       _p(dg), _p(dbt), acc, N, D, H, W, C, ws, wsb,
+                                                       self._stream(dout)), "siv_conv1_bnact_wgrad_bits")
+        return dw, db, dg, dbt
 
     # ---- BatchNorm + LeakyReLU folded into the Cin -> 1 convolution behind them ---------------------
     def bnact_conv_to1_supported(self, x) -> bool:

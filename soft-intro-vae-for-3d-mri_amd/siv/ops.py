@@ -29,6 +29,9 @@ OVERLAP_WGRAD = os.environ.get("SIV_OVERLAP_WGRAD", "1") != "0"
 # parameter and pass.  This is the contract of ``loss.backward()`` (gradients end up in ``.grad``);
 # ``torch.autograd.grad`` on such parameters would get ``None`` -- set DIRECT_GRAD = False for that.
 DIRECT_GRAD = True
+# the fused encoder stem keeps its dropout / activation decisions as two bits per element for its backward
+# pass (0: the backward passes redraw or re-read the mask and always form the convolution output's gradient)
+STEM_BITS = os.environ.get("SIV_STEM_BITS", "1") != "0"
 
 
 def _grad_buf(p):
@@ -406,22 +409,34 @@ def conv_bn_act(x, conv, bn, slope: float, ups: int = 1, pool: int = 1, residual
 class _Conv1BnAct(Function):
     """Conv3d(1, C, 3, 1, 1) -> BatchNorm3d -> LeakyReLU -> Dropout (the encoder stem) with the convolution
     output recomputed by every pass instead of stored; backward hands the gradient of that output to the
-    ordinary weight / input gradient kernels of the convolution."""
+    ordinary weight / input gradient kernels of the convolution -- or, where the input needs no gradient
+    (data, detached reconstructions), forms the parameter gradients in one pass over ``dout`` without it.
+    The training-mode forward pass leaves its dropout / activation decisions as two bits per element for
+    the backward pass (backends with ``stem_bits``)."""
 
     @staticmethod
     def forward(ctx, x, w, bias, gamma, beta, keep, bn, p, slope, train, emit_bf16=False):
         B = get_backend()
+        want_bits = bool(STEM_BITS and train and getattr(B, "stem_bits", False) and any(ctx.needs_input_grad))
+        opts = {}
+        if emit_bf16:
+            opts["emit_bf16"] = True
+        if want_bits:
+            opts["emit_bits"] = True
         res = B.conv1_bnact_fwd(x, w, bias, gamma, beta, keep, p, slope, bn.eps, train,
                                 bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                BN_MOMENTUM if bn.momentum is None else bn.momentum,
-                                **({"emit_bf16": True} if emit_bf16 else {}))
+                                BN_MOMENTUM if bn.momentum is None else bn.momentum, **opts)
         out, mean, var = res[:3]
         oh = res[3] if emit_bf16 else None      # bf16 copy of the output, for the convolution that consumes it
+        ctx.bits = res[-1] if want_bits else None
         if oh is not None:
             activations.count_native(out)
             ctx.mark_non_differentiable(oh)
             ctx.set_materialize_grads(False)        # no zero "gradient" tensor for the bf16 copy
         ctx.mask_key = None if keep is None or torch.is_tensor(keep) else keep   # a mask drawn in-kernel
+        if want_bits:                            # the bits carry the mask; p = 0 where nothing was dropped
+            p = float(p) if keep is not None else 0.0
+            ctx.mask_key, keep = None, None
         ctx.save_for_backward(x, w, bias, mean, var, gamma, beta, keep if ctx.mask_key is None else None)
         ctx.cfg = (p, slope, bn.eps, train)
         ctx.bufs = (_grad_buf(w), _grad_buf(bias), _grad_buf(gamma), _grad_buf(beta))
@@ -442,12 +457,26 @@ class _Conv1BnAct(Function):
         B = get_backend()
         dx = dw = dcb = dg = db = None
         want_aff = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        want_cb = bias is not None and ctx.needs_input_grad[2]
+        bits, ctx.bits = ctx.bits, None
+        if bits is not None and not ctx.needs_input_grad[0]:
+            # parameters only: no gradient of the convolution output, one pass over dout
+            need = ctx.needs_input_grad
+            if (need[1] and need[3] and need[4] and (bias is None or need[2]) and w_buf is not None and
+                    g_buf is not None and b_buf is not None and (bias is None or cb_buf is not None)):
+                B.conv1_bnact_wgrad(dout, x, w, bias, mean, var, gamma, bits, p, slope, eps, w_buf, cb_buf, g_buf, b_buf)
+                return (None,) * 11
+            dw, dcb, dg, db = B.conv1_bnact_wgrad(dout, x, w, bias, mean, var, gamma, bits, p, slope, eps,
+                                                  want_bias=want_cb, want_affine=want_aff)
+            return (None, dw if need[1] else None, dcb if want_cb else None, dg if need[3] else None,
+                    db if need[4] else None, None, None, None, None, None, None)
+        kw = {"bits": bits} if bits is not None else {}
         if ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and g_buf is not None and b_buf is not None:
             dy, _, _ = B.conv1_bnact_bwd(dout, x, w, bias, mean, var, gamma, beta, keep, p, slope, eps, True,
-                                         g_buf, b_buf)
+                                         g_buf, b_buf, **kw)
         else:
-            dy, dg, db = B.conv1_bnact_bwd(dout, x, w, bias, mean, var, gamma, beta, keep, p, slope, eps, want_aff)
-        want_cb = bias is not None and ctx.needs_input_grad[2]
+            dy, dg, db = B.conv1_bnact_bwd(dout, x, w, bias, mean, var, gamma, beta, keep, p, slope, eps, want_aff,
+                                           **kw)
         if ctx.needs_input_grad[1] or want_cb:
             direct = ctx.needs_input_grad[1] and w_buf is not None and (not want_cb or cb_buf is not None)
             if direct:

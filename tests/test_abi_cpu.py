@@ -30,10 +30,12 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"libsiv.so does not export {name}"
     # the ctypes table binds everything that takes device pointers
-    helpers = {"siv_last_error", "siv_version", "siv_workspace_bytes", "siv_last_conv_kernel", "siv_pack_cache_hits"}
+    helpers = {"siv_last_error", "siv_version", "siv_workspace_bytes", "siv_last_conv_kernel", "siv_pack_cache_hits",
+               "siv_conv1_bnact_bits_bytes"}
     assert set(declared_symbols()) - helpers == set(_lib.SIGNATURES)
     assert lib.siv_version() >= 100
     assert lib.siv_workspace_bytes() >= (64 << 20)
+    assert lib.siv_conv1_bnact_bits_bytes(2, 3, 4, 5, 64) == 2 * 3 * 4 * 5 * 16
 
 
 def test_argument_validation_needs_no_gpu():

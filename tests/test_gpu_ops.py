@@ -743,6 +743,103 @@ def test_conv1_bnact_draws_the_mask_it_would_have_read(B, C, dims, n, p, epoch):
         assert torch.equal(a_, b_), "operator: " + what
 
 
+@pytest.mark.parametrize("C,dims,n,p,draw", [(64, (9, 10, 11), 2, 0.2, False), (16, (16, 24, 20), 1, 0.0, False),
+                                             (64, (8, 12, 8), 3, 0.35, True), (12, (6, 7, 5), 2, 0.5, False),
+                                             (64, (20, 24, 36), 2, 0.35, True)])
+def test_conv1_bnact_bits_and_weight_only_backward(B, C, dims, n, p, draw):
+    """The stem's forward pass with its dropout / activation decisions left as two bits per element
+    (siv_conv1_bnact_fwd_bits), the backward that takes the mask from them (siv_conv1_bnact_bwd_bits: bit-identical
+    to the mask-tensor form) and the weight-only backward that never forms the gradient of the convolution
+    output (siv_conv1_bnact_wgrad_bits): dw, dgamma, dbeta against float64 autograd of the composition
+    (models/models.py:91-96) and against the two-step path (bwd, then the convolution's weight gradient);
+    the autograd operator with an input that needs no gradient, with plain .grad tensors and with the
+    optimiser's flat buffers, against the unfused operators."""
+    import siv.ops as ops
+    from siv.optim import FlatAdam
+    from siv.rng import PhiloxKeep
+    gen = torch.Generator().manual_seed(2 * C + dims[0] + n)
+    D, H, W = dims
+    slope, eps = 0.2, 1e-5
+    x = torch.rand(n, 1, D, H, W, generator=gen)
+    w, b = rnd(gen, C, 1, 3, 3, 3, scale=0.4), rnd(gen, C) * 2
+    gamma, beta = 1 + 0.3 * rnd(gen, C), 0.2 * rnd(gen, C)
+    dout = rnd(gen, n, C, D, H, W)
+    if p > 0 and draw:
+        key = PhiloxKeep(seed=0x51ED270B, stream_id=(3 << 40) | 5, epoch=None)
+        keep = key.materialise((n, C, D, H, W), p, "cuda").cpu()
+        keep_arg = key
+    else:
+        keep = (torch.rand(n, C, D, H, W, generator=gen) >= p).to(torch.uint8) if p > 0 else None
+        keep_arg = dev(keep)
+    # float64 reference
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    gd, btd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yd = F.conv3d(x.double(), wd, bd, padding=1)
+    mu = yd.mean(dim=(0, 2, 3, 4), keepdim=True)
+    vr = yd.var(dim=(0, 2, 3, 4), unbiased=False, keepdim=True)
+    zd = (yd - mu) / torch.sqrt(vr + eps) * gd.view(1, -1, 1, 1, 1) + btd.view(1, -1, 1, 1, 1)
+    act = F.leaky_relu(zd, slope)
+    ref = act * keep.double() / (1 - p) if keep is not None else act
+    ref.backward(dout.double())
+
+    def stats():
+        return torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.tensor(0, device="cuda")
+    xs, ws, bs, gs, bts, ds = dev(x), dev(w), dev(b), dev(gamma), dev(beta), dev(dout)
+    out0, mean0, var0 = B.conv1_bnact_fwd(xs, ws, bs, gs, bts, keep_arg, p, slope, eps, True, *stats(), 0.1)
+    out, mean, var, bits = B.conv1_bnact_fwd(xs, ws, bs, gs, bts, keep_arg, p, slope, eps, True, *stats(), 0.1,
+                                             emit_bits=True)
+    assert torch.equal(out, out0) and torch.equal(mean, mean0) and torch.equal(var, var0)
+    # layout: one byte per channel quad of a voxel, bit j = kept, bit 4 + j = BatchNorm output > 0
+    assert bits.dtype == torch.uint8 and bits.numel() == n * D * H * W * C // 4
+    bq = bits.view(n, D, H, W, C // 4).cpu().long()
+    kept = torch.stack([(bq >> j) & 1 for j in range(4)], dim=-1).reshape(n, D, H, W, C).permute(0, 4, 1, 2, 3)
+    posb = torch.stack([(bq >> (4 + j)) & 1 for j in range(4)], dim=-1).reshape(n, D, H, W, C).permute(0, 4, 1, 2, 3)
+    assert torch.equal(kept, keep.long() if keep is not None else torch.ones_like(kept))
+    near = zd.detach().abs() < 1e-4 * float(zd.detach().abs().max())        # sign undecided within rounding
+    assert bool(((posb == 1) == (zd.detach() > 0))[~near].all())
+    # the mask from the bits: same results as from the mask tensor / the generator, bit for bit
+    dy0, dg0, db0 = B.conv1_bnact_bwd(ds, xs, ws, bs, mean, var, gs, bts, keep_arg, p, slope, eps, True)
+    dy1, dg1, db1 = B.conv1_bnact_bwd(ds, xs, ws, bs, mean, var, gs, bts, None, p, slope, eps, True, bits=bits)
+    assert torch.equal(dy0, dy1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    # weight-only backward
+    dw, dcb, dg, db = B.conv1_bnact_wgrad(ds, xs, ws, bs, mean, var, gs, bits, p, slope, eps)
+    check(dw, wd.grad.float(), "dw against float64")
+    check(dg, gd.grad.float(), "dgamma against float64")
+    check(db, btd.grad.float(), "dbeta against float64")
+    dw2, _ = B.conv3d_k3_wgrad(xs, dy0, 1, True)
+    check(dw, dw2, "dw against the two-step path", tol=2e-5)
+    check(dg, dg0, "dgamma against the two-step path", tol=2e-5)
+    check(db, db0, "dbeta against the two-step path", tol=1e-6)
+    assert float(dcb.abs().max()) <= 1e-3 * float(dw.abs().max()) + 1e-6      # BatchNorm cancels the convolution bias
+    # accumulating form
+    acc = [torch.full_like(t, 0.5) for t in (dw, dcb, dg, db)]
+    B.conv1_bnact_wgrad(ds, xs, ws, bs, mean, var, gs, bits, p, slope, eps, *acc)
+    for a_, r_, what in zip(acc, (dw, dcb, dg, db), ("dw", "dbias", "dgamma", "dbeta")):
+        check(a_, 0.5 + r_, "accumulated " + what, tol=1e-6)
+
+    # the autograd operator on an input that needs no gradient
+    outs = []
+    for mode in ("fused", "fused-flat", "unfused"):
+        bn = torch.nn.BatchNorm3d(C).to("cuda").train()
+        conv = torch.nn.Conv3d(1, C, 3, 1, 1).to("cuda")
+        with torch.no_grad():
+            bn.weight.copy_(gs); bn.bias.copy_(bts); conv.weight.copy_(ws); conv.bias.copy_(bs)
+        if mode == "fused-flat":
+            opt = FlatAdam(list(conv.parameters()) + list(bn.parameters()), lr=1e-3)
+        fn = ops.conv_bn_act if mode == "unfused" else ops.conv1_bn_act
+        o = fn(xs, conv, bn, slope, keep=keep_arg if mode != "unfused" else dev(keep), p=p, train=True)
+        o.backward(ds)
+        torch.cuda.synchronize()
+        outs.append((o.detach(), conv.weight.grad.clone(), conv.bias.grad.clone(), bn.weight.grad.clone(),
+                     bn.bias.grad.clone()))
+    for k, what in enumerate(("out", "dw", "dbias", "dgamma", "dbeta")):
+        assert torch.equal(outs[0][k], outs[1][k]), "flat buffers: " + what
+        if what == "dbias":
+            assert float(outs[0][k].abs().max()) <= 1e-3 * float(outs[0][1].abs().max()) + 1e-6
+            continue
+        check(outs[0][k], outs[2][k], "operator: " + what, tol=5e-5, max_outliers=2)
+
+
 @pytest.mark.parametrize("dims,n", [((16, 24, 32), 2), ((19, 44, 36), 1), ((16, 12, 16), 3)])
 def test_bnact_conv_to1_matches_separate_ops(B, dims, n):
     """BatchNorm + LeakyReLU folded into the 64 -> 1 output convolution (models/models.py:76-78,137):
