@@ -1437,13 +1437,13 @@ __global__ __launch_bounds__(256) void flat_sum_partial(const float* __restrict_
     acc = block_sum_256(acc, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
-__global__ void flat_sum_final(const float* __restrict__ part, int nblk, float* __restrict__ out,
-                               int accumulate) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double s = 0.0;
-        for (int b = 0; b < nblk; ++b) s += (double)part[b];
-        *out = accumulate ? *out + (float)s : (float)s;
-    }
+// one wave: lanes stride over the partials, fixed-order wave sum (a single thread took 50 us for 1024 partials)
+__global__ __launch_bounds__(64) void flat_sum_final(const float* __restrict__ part, int nblk, float* __restrict__ out,
+                                                     int accumulate) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += (double)part[b];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) *out = accumulate ? *out + (float)s : (float)s;
 }
 
 bool k3_thin_supported(int Cin, int Cout) {

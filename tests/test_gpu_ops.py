@@ -743,10 +743,14 @@ def test_conv1_bnact_draws_the_mask_it_would_have_read(B, C, dims, n, p, epoch):
         assert torch.equal(a_, b_), "operator: " + what
 
 
-@pytest.mark.parametrize("C,dims,n,p,draw", [(64, (9, 10, 11), 2, 0.2, False), (16, (16, 24, 20), 1, 0.0, False),
-                                             (64, (8, 12, 8), 3, 0.35, True), (12, (6, 7, 5), 2, 0.5, False),
-                                             (64, (20, 24, 36), 2, 0.35, True)])
-def test_conv1_bnact_bits_and_weight_only_backward(B, C, dims, n, p, draw):
+@pytest.mark.parametrize("C,dims,n,p,draw,smooth", [
+    (64, (9, 10, 11), 2, 0.2, False, False), (16, (16, 24, 20), 1, 0.0, False, False),
+    (64, (8, 12, 8), 3, 0.35, True, False), (12, (6, 7, 5), 2, 0.5, False, False),
+    (64, (20, 24, 36), 2, 0.35, True, False),
+    # smooth volumes under zero-sum (edge detector) filters: the case in which the filter's response to the
+    # input's tap correlation is a small difference of large terms
+    (64, (40, 48, 40), 2, 0.35, True, True), (64, (24, 24, 40), 1, 0.0, False, True)])
+def test_conv1_bnact_bits_and_weight_only_backward(B, C, dims, n, p, draw, smooth):
     """The stem's forward pass with its dropout / activation decisions left as two bits per element
     (siv_conv1_bnact_fwd_bits), the backward that takes the mask from them (siv_conv1_bnact_bwd_bits: bit-identical
     to the mask-tensor form) and the weight-only backward that never forms the gradient of the convolution
@@ -762,6 +766,11 @@ def test_conv1_bnact_bits_and_weight_only_backward(B, C, dims, n, p, draw):
     slope, eps = 0.2, 1e-5
     x = torch.rand(n, 1, D, H, W, generator=gen)
     w, b = rnd(gen, C, 1, 3, 3, 3, scale=0.4), rnd(gen, C) * 2
+    if smooth:
+        zz, yy, xx = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing="ij")
+        base = 0.5 + 0.25 * torch.sin(zz / 7.0) * torch.cos(yy / 9.0) + 0.2 * torch.sin(xx / 11.0 + 0.3)
+        x = (base.float()[None, None] * (0.8 + 0.2 * torch.rand(n, 1, 1, 1, 1, generator=gen)) + 0.01 * x).clamp(0, 1)
+        w = w - w.mean(dim=(1, 2, 3, 4), keepdim=True)
     gamma, beta = 1 + 0.3 * rnd(gen, C), 0.2 * rnd(gen, C)
     dout = rnd(gen, n, C, D, H, W)
     if p > 0 and draw:
@@ -803,9 +812,13 @@ def test_conv1_bnact_bits_and_weight_only_backward(B, C, dims, n, p, draw):
     assert torch.equal(dy0, dy1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
     # weight-only backward
     dw, dcb, dg, db = B.conv1_bnact_wgrad(ds, xs, ws, bs, mean, var, gs, bits, p, slope, eps)
-    check(dw, wd.grad.float(), "dw against float64")
-    check(dg, gd.grad.float(), "dgamma against float64")
-    check(db, btd.grad.float(), "dbeta against float64")
+    # (smooth volumes put many BatchNorm outputs within rounding of zero: an element whose sign differs between
+    # fp32 and float64 moves a sum by its whole gradient, so float64 is the looser of the two comparisons there;
+    # the two-step path shares the decisions and must agree closely)
+    tol64, out64 = (1e-3, 2) if smooth else (TOL, 0)
+    check(dw, wd.grad.float(), "dw against float64", tol=tol64, max_outliers=out64)
+    check(dg, gd.grad.float(), "dgamma against float64", tol=tol64, max_outliers=out64)
+    check(db, btd.grad.float(), "dbeta against float64", tol=tol64, max_outliers=out64)
     dw2, _ = B.conv3d_k3_wgrad(xs, dy0, 1, True)
     check(dw, dw2, "dw against the two-step path", tol=2e-5)
     check(dg, dg0, "dgamma against the two-step path", tol=2e-5)
