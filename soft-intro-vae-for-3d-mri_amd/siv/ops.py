@@ -458,7 +458,7 @@ class _Conv1BnAct(Function):
         dx = dw = dcb = dg = db = None
         want_aff = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         want_cb = bias is not None and ctx.needs_input_grad[2]
-        bits, ctx.bits = ctx.bits, None
+        bits = ctx.bits
         if bits is not None and not ctx.needs_input_grad[0]:
             # parameters only: no gradient of the convolution output, one pass over dout
             need = ctx.needs_input_grad
