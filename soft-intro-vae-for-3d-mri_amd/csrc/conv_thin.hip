@@ -1143,6 +1143,8 @@ __global__ __launch_bounds__(256) void thin_wg_k(const float* __restrict__ a,
 // GBF: g points at the bf16 copy of the (raw) multi-channel operand.
 // SB: g is the gradient behind the stem's Dropout and LeakyReLU; every element is first taken back through
 // them with the two bits the stem's forward pass left per element (stem_bn_k): g * keep / (1 - p) * act'(z).
+// (Four waves per SIMD at 128 registers: the plain form spills 12 bytes per lane and gains 6-10 %, the forms with
+// a prologue spill 36-96 bytes and lose 4-14 %; the model uses only those.)
 template <bool BN, bool GBF, bool SB = false>
 __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict__ a,
                                                       const float* __restrict__ g,
@@ -1185,38 +1187,49 @@ __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict
     if (b1 > nbricks) b1 = nbricks;
     int buf = 0;
     float hr[TH_PER_THREAD];
-    if (b0 < b1) halo1_fetch(a, hr, (int)b0, nbd, nbh, nbw, D, H, W);
+    // The multi-channel operand is fetched one group of four brick rows ahead of its use, ACROSS bricks: the
+    // first group of brick b + 1 is requested while the last group of brick b is multiplied (its addresses do
+    // not depend on the halo image the barrier waits for), so no group's latency is paid in the open.
+    // group u (0..15) of a brick plane: brick row u >> 1, voxels 4 (u & 1) + kk
+    auto load4 = [&](float4 (&dst)[4], uint32_t (&bd)[4], int c4, int n, int z0, int y0, int x0) {
+        const int gz = z0 + wv;
+        const long gbase = ((((long)n * D + gz) * H + y0) * W + x0) * C + 4 * q;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int dy = 2 * c4 + (u >> 1), dx = 4 * (u & 1) + kk;
+            const bool ok = qok && gz < D && y0 + dy < H && x0 + dx < W;
+            // masked lanes read the start of the tensor (no branch around the load) and are
+            // zeroed where the value is used, so nothing waits for the load here
+            const long e = ok ? gbase + (long)(dy * W + dx) * C : 0;
+            dst[u] = thin_ld4<GBF>(g, e);
+            if (SB) bd[u] = sbits[e >> 2];              // the decision byte of (this voxel, channel quad q)
+        }
+    };
+    float4 av[2][4];
+    uint32_t ab[2][4];
+    int n = 0, z0 = 0, y0 = 0, x0 = 0;                 // the brick being multiplied
+    if (b0 < b1) {
+        halo1_fetch(a, hr, (int)b0, nbd, nbh, nbw, D, H, W);
+        brick_coords((int)b0, nbd, nbh, nbw, n, z0, y0, x0);
+        load4(av[0], ab[0], 0, n, z0, y0, x0);
+    }
     for (long br = b0; br < b1; ++br, buf ^= 1) {
-        int n, z0, y0, x0;
-        brick_coords((int)br, nbd, nbh, nbw, n, z0, y0, x0);
+        int nn = 0, nz0 = 0, ny0 = 0, nx0 = 0;          // the brick after it
         // two halo images: a wave still multiplying the previous brick reads the other one
         halo1_put(hal[buf], hr);
         __syncthreads();
         if (br + 1 < b1) halo1_fetch(a, hr, (int)br + 1, nbd, nbh, nbw, D, H, W);
         __builtin_amdgcn_sched_barrier(0);
-        const int gz = z0 + wv;
-        if (gz >= D) continue;
-        const long gbase = ((((long)n * D + gz) * H + y0) * W + x0) * C + 4 * q;
+        const bool zin = z0 + wv < D;                   // a plane below the volume contributes zeros
         const float* hp = hal[buf] + wv * TH_H * TH_W + kk;
-        // group u (0..15): brick row u >> 1, voxels 4 (u & 1) + kk
-        auto load4 = [&](float4 (&dst)[4], uint32_t (&bd)[4], int c4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int dy = 2 * c4 + (u >> 1), dx = 4 * (u & 1) + kk;
-                const bool ok = qok && y0 + dy < H && x0 + dx < W;
-                // masked lanes read the start of the tensor (no branch around the load) and are
-                // zeroed where the value is used, so nothing waits for the load here
-                const long e = ok ? gbase + (long)(dy * W + dx) * C : 0;
-                dst[u] = thin_ld4<GBF>(g, e);
-                if (SB) bd[u] = sbits[e >> 2];              // the decision byte of (this voxel, channel quad q)
-            }
-        };
-        float4 av[2][4];
-        uint32_t ab[2][4];
-        load4(av[0], ab[0], 0);
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
-            if (c4 < 3) load4(av[(c4 + 1) & 1], ab[(c4 + 1) & 1], c4 + 1);
+            if (c4 < 3) {
+                load4(av[(c4 + 1) & 1], ab[(c4 + 1) & 1], c4 + 1, n, z0, y0, x0);
+            } else if (br + 1 < b1) {
+                brick_coords((int)br + 1, nbd, nbh, nbw, nn, nz0, ny0, nx0);
+                load4(av[0], ab[0], 0, nn, nz0, ny0, nx0);
+            }
             __builtin_amdgcn_sched_barrier(0);          // keep the loads ahead of the products
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1225,7 +1238,7 @@ __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict
 #pragma unroll
                 for (int cg = 0; cg < 2; ++cg)
                     bv[cg] = btap[cg] ? hp[dy * TH_W + dx0 + toff[cg]] : bconst[cg];
-                const bool ok = qok && y0 + dy < H && x0 + dx0 + kk < W;
+                const bool ok = qok && zin && y0 + dy < H && x0 + dx0 + kk < W;
                 float4 v = av[c4 & 1][u];
                 if (BN)
                     v = make_float4(bn_act1(v.x, ca.x, cb.x, bn.slope), bn_act1(v.y, ca.y, cb.y, bn.slope),
@@ -1248,6 +1261,7 @@ __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict
                 }
             }
         }
+        n = nn; z0 = nz0; y0 = ny0; x0 = nx0;
     }
     // combine the four waves in fixed order: wave w adds its tiles into the LDS image in round w.
     // Lane (q, kk), register e of acc[j][cg] holds channel 4 (4 kk + e) + j under tap q + 16 cg.
