@@ -168,7 +168,7 @@ int siv_conv1_bnact_bwd(const float* dout, const float* x, const float* w, const
  *   (accumulate = 1) added -- straight from dout, x and bits.  The gradient dy of the convolution output is
  *   never formed: with dz = dout * keep / (1 - p) * act'(z) and the input's own 28 x 28 tap correlation,
  *   BatchNorm's backward and the weight gradient are linear maps of T[c][tap] = sum_v dz[v][c] x[v + tap]
- *   (formulas at stem_autocorr_k in csrc/conv_thin.hip); sums over blocks and the combination in double
+ *   (formulas at stem_wg_reduce_k in csrc/conv_thin.hip); sums over blocks and the combination in double
  *   precision.  Equals siv_conv1_bnact_bwd followed by siv_conv3d_k3_wgrad up to fp32 rounding. */
 size_t siv_conv1_bnact_bits_bytes(int N, int D, int H, int W, int Cout);
 int siv_conv1_bnact_fwd_bits(const float* x, const float* w, const float* bias, const float* gamma,

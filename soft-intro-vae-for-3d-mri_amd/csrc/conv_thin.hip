@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void one_to_c_k(const float* __restrict__ a,
 // output.
 // ---------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16t __attribute__((ext_vector_type(16)));
 
 // Four consecutive channels of a voxel held as bf16 (8 bytes): the storage format of activations that are
 // kept for the backward pass when bf16 activation storage is on.  `e` is the ELEMENT index of the first channel.
@@ -1152,9 +1153,11 @@ __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict
                                                       int C, int nbd, int nbh, int nbw,
                                                       int bricks_per_block, BnPrologue bn,
                                                       const uint8_t* __restrict__ sbits = nullptr,
-                                                      float dscale = 1.f) {
+                                                      float dscale = 1.f, float* __restrict__ rpart = nullptr) {
+    // SB also forms the tap correlation of the single-channel operand (which the stem's weight-only backward
+    // needs beside T) from the halo images it stages anyway: rpart[block][32][32]
     __shared__ float hal[2][TH_V];
-    __shared__ float red[64 * 28];
+    __shared__ float red[64 * 28];                      // T image of the block (1792 floats), then the 32 x 32 tap correlation
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = lane & 15, kk = lane >> 4;
     const bool qok = 4 * q < C;
@@ -1181,6 +1184,14 @@ __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int cg = 0; cg < 2; ++cg) acc[j][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // SB: P'^T P' of the halo (lane = (column t32, voxel k32) of a 32x32x2 instruction, rows and columns = taps)
+    f32x16t racc;
+    const int t32 = lane & 31, k32 = lane >> 5;
+    const int roff = t32 < 27 ? ((t32 / 9) * TH_H + (t32 / 3) % 3) * TH_W + t32 % 3 : 0;
+    if (SB) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+    }
     const long nbricks = (long)N * nbd * nbh * nbw;
     const long b0 = (long)blockIdx.x * bricks_per_block;
     long b1 = b0 + bricks_per_block;
@@ -1259,6 +1270,18 @@ __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict
                     acc[2][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, bv[cg], acc[2][cg], 0, 0, 0);
                     acc[3][cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, bv[cg], acc[3][cg], 0, 0, 0);
                 }
+                if (SB) {
+                    // two voxel pairs of the plane per group: rows 2 c4 + (u >> 1), x = 4 (u & 1) + 2 i + k32
+                    const float* rp = hal[buf] + wv * TH_H * TH_W + roff;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int rx = 4 * (u & 1) + 2 * i + k32;
+                        float pv = rp[dy * TH_W + rx];
+                        pv = t32 < 27 ? pv : (t32 == 27 ? 1.f : 0.f);
+                        pv = (zin && y0 + dy < H && x0 + rx < W) ? pv : 0.f;
+                        racc = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, pv, racc, 0, 0, 0);
+                    }
+                }
             }
         }
         n = nn; z0 = nz0; y0 = ny0; x0 = nx0;
@@ -1287,6 +1310,22 @@ __global__ __launch_bounds__(256, 3) void thin_wg_mfma_k(const float* __restrict
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < C * 28; idx += 256) pp[idx] = red[idx];
+    if (SB) {       // the tap correlation, the four waves in fixed order: register r of lane (t, k) is row (r & 3) + 8 (r >> 2) + 4 k
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            __syncthreads();
+            if (wv == w) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * k32;
+                    red[row * 32 + t32] = w == 0 ? racc[r] : red[row * 32 + t32] + racc[r];
+                }
+            }
+        }
+        __syncthreads();
+        float* rr = rpart + (long)blockIdx.x * 1024;
+        for (int idx = threadIdx.x; idx < 1024; idx += 256) rr[idx] = red[idx];
+    }
 }
 
 // mode 0 (stem): dw[c*27+tap] = T[c][tap], dbias[c] = T[c][27]
@@ -1319,68 +1358,12 @@ __global__ __launch_bounds__(256) void thin_wg_reduce(const float* __restrict__ 
 //   Q        = inv * (sum_t w[c][t] T[c][t] + (bias - mean) S)
 //   X[c][t]  = sum_v xhat[v][c] p[v][t] = inv * (sum_t' w[c][t'] R[t'][t] + (bias - mean) A[t])
 //   dW[c][t] = ca * (T[c][t] - S / M * A[t] - Q / M * X[c][t])
-// where R[t'][t] = sum_v p[v][t'] p[v][t] and A[t] = sum_v p[v][t] depend on the single-channel input alone
-// (stem_autocorr_k: P^T P with a column of ones appended, 28 x 28, on the matrix pipe).  The sums over the
-// per-block partials and the combination run in double precision.
+// where R[t'][t] = sum_v p[v][t'] p[v][t] and A[t] = sum_v p[v][t] depend on the single-channel input alone:
+// P'^T P' with P'[v] = (the 27 taps, 1, 0, 0, 0, 0), 32x32x2 matrix instructions whose two operands are the same
+// register, formed by the same pass from the halo images it stages anyway (as a kernel of its own it took
+// 0.11 ms; inside the HBM-bound pass it is free).  The sums over the per-block partials and the combination
+// run in double precision.
 // ---------------------------------------------------------------------------------
-typedef float f32x16t __attribute__((ext_vector_type(16)));
-
-// part[block][32][32] = sum over the block's bricks of P'^T P', P'[v] = (27 taps of the halo, 1, 0, 0, 0, 0).
-// Wave wv owns plane wv of every brick; one 32x32x2 instruction takes two voxels, both operands are the same
-// register (lane = (column, voxel)).
-__global__ __launch_bounds__(256, 3) void stem_autocorr_k(const float* __restrict__ a, float* __restrict__ part,
-                                                          int N, int D, int H, int W, int nbd, int nbh, int nbw,
-                                                          int bricks_per_block) {
-    __shared__ float hal[2][TH_V];
-    __shared__ float red[1024];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int t = lane & 31, k = lane >> 5;
-    const int toff = t < 27 ? ((t / 9) * TH_H + (t / 3) % 3) * TH_W + t % 3 : 0;
-    const float cst = t == 27 ? 1.f : 0.f;
-    f32x16t acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const long nbricks = (long)N * nbd * nbh * nbw;
-    const long b0 = (long)blockIdx.x * bricks_per_block;
-    long b1 = b0 + bricks_per_block;
-    if (b1 > nbricks) b1 = nbricks;
-    int buf = 0;
-    float hr[TH_PER_THREAD];
-    if (b0 < b1) halo1_fetch(a, hr, (int)b0, nbd, nbh, nbw, D, H, W);
-    for (long br = b0; br < b1; ++br, buf ^= 1) {
-        int n, z0, y0, x0;
-        brick_coords((int)br, nbd, nbh, nbw, n, z0, y0, x0);
-        halo1_put(hal[buf], hr);
-        __syncthreads();
-        if (br + 1 < b1) halo1_fetch(a, hr, (int)br + 1, nbd, nbh, nbw, D, H, W);
-        __builtin_amdgcn_sched_barrier(0);
-        if (z0 + wv >= D) continue;
-        const float* hp = hal[buf] + wv * TH_H * TH_W + toff;
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) {                  // voxels 2 i + k of the plane: row i >> 2, x 2 (i & 3) + k
-            const int dy = i >> 2, dx = 2 * (i & 3) + k;
-            const bool ok = y0 + dy < H && x0 + dx < W;
-            float v = t < 27 ? hp[dy * TH_W + dx] : cst;
-            v = ok ? v : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v, v, acc, 0, 0, 0);
-        }
-    }
-    // the four waves in fixed order; register r of lane (t, k) is row (r & 3) + 8 (r >> 2) + 4 k, column t
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        __syncthreads();
-        if (wv == w) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * k;
-                red[row * 32 + t] = w == 0 ? acc[r] : red[row * 32 + t] + acc[r];
-            }
-        }
-    }
-    __syncthreads();
-    float* pp = part + (long)blockIdx.x * 1024;
-    for (int idx = threadIdx.x; idx < 1024; idx += 256) pp[idx] = red[idx];
-}
 
 // Td[i] = sum_b tpart[b][i] (i < C * 28), Rd[i] = sum_b rpart[b][i] (i < 1024): one wave per element, double
 __global__ __launch_bounds__(256) void stem_wg_reduce_k(const float* __restrict__ tpart, int nblk_t, int nt,
@@ -1669,7 +1652,7 @@ int stem_bnact_bwd_launch(const float* dout, const float* x, const float* w, con
 
 // Weight-only backward of the same (dw, dbias of the convolution, dgamma, dbeta) from the gradient behind the
 // dropout and the bits of the forward pass: one pass over dout, one over the single-channel input; the
-// gradient of the convolution output is never formed (algebra at stem_autocorr_k).
+// gradient of the convolution output is never formed (algebra at stem_wg_reduce_k).
 int stem_bnact_wgrad_launch(const float* dout, const float* x, const float* w, const float* bias, const float* mean,
                             const float* var, const float* gamma, const void* bits, float p, float slope, float eps,
                             float* dw, float* dbias, float* dgamma, float* dbeta, int accumulate, int N, int D,
@@ -1697,11 +1680,10 @@ int stem_bnact_wgrad_launch(const float* dout, const float* x, const float* w, c
     double* Rd = (double*)((char*)ws + tpart_bytes + rpart_bytes + td_bytes);
     BnPrologue bn{};
     bn.slope = slope;
+    // one pass: T from dout and the bits, the input's tap correlation from the halo images it stages anyway
     thin_wg_mfma_k<false, false, true><<<(unsigned)nblk, 256, 0, s>>>(x, dout, tpart, N, D, H, W, C, nbd, nbh, nbw, bpb, bn,
-                                                                     (const uint8_t*)bits, 1.0f / (1.0f - p));
+                                                                     (const uint8_t*)bits, 1.0f / (1.0f - p), rpart);
     SIV_CHECK_LAUNCH("conv1_bnact_wgrad(gradient pass)");
-    stem_autocorr_k<<<(unsigned)nblk, 256, 0, s>>>(x, rpart, N, D, H, W, nbd, nbh, nbw, bpb);
-    SIV_CHECK_LAUNCH("conv1_bnact_wgrad(input pass)");
     stem_wg_reduce_k<<<(C * 28 + 1024 + 3) / 4, 256, 0, s>>>(tpart, (int)nblk, C * 28, rpart, (int)nblk, Td, Rd);
     SIV_CHECK_LAUNCH("conv1_bnact_wgrad(reduce)");
     stem_wg_final_k<<<C, 64, 0, s>>>(Td, Rd, w, bias, mean, var, gamma, eps, (double)((long)N * D * H * W), dw, dbias,
