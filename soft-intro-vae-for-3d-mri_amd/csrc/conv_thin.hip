@@ -408,7 +408,10 @@ __global__ __launch_bounds__(256, 3) void tail_bn_bwd_k(const float* __restrict_
 // ---------------------------------------------------------------------------------
 enum { SM_STATS = 0, SM_APPLY = 1, SM_BSUM = 2, SM_BAPP = 3 };
 
-template <int MODE, bool BITS = false>
+// MASK / EMIT: -1 = decided at run time from the arguments; 0, 1, 2 = compiled for no dropout / a mask tensor /
+// the generator, and without / with the bf16 copy (the production forms: the other branches are half of the
+// apply pass's 50 KB of code otherwise)
+template <int MODE, bool BITS = false, int MASK = -1, int EMIT = -1>
 __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                                                     const float* __restrict__ w,
                                                     const float* __restrict__ bias, BnPrologue bn,
@@ -424,8 +427,11 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
     __shared__ float hal[2][TH_V];
     constexpr bool BITS_IN = BITS && (MODE == SM_BSUM || MODE == SM_BAPP);
     // dropout: a mask tensor (keep), or the mask drawn here from the element index (rk.on), or none
-    const bool masked = MODE != SM_STATS && (BITS_IN || keep != nullptr || rk.on);
-    const uint64_t rsid = (rk.on && rk.epoch) ? rk.sid + *rk.epoch * SIV_EPOCH_STRIDE : rk.sid;
+    const bool has_keep = MASK < 0 ? keep != nullptr : MASK == 1;
+    const bool has_rk = MASK < 0 ? rk.on != 0 : MASK == 2;
+    const bool emit = MODE == SM_APPLY && (EMIT < 0 ? out_bf16 != nullptr : EMIT == 1);
+    const bool masked = MODE != SM_STATS && (BITS_IN || has_keep || has_rk);
+    const uint64_t rsid = (has_rk && rk.epoch) ? rk.sid + *rk.epoch * SIV_EPOCH_STRIDE : rk.sid;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int q = lane & 15, kk = lane >> 4;
     const bool qok = 4 * q < C;
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                 // what the pass reads goes out first (clamped, unconditional) and has the products to arrive
                 if (MODE == SM_BSUM || MODE == SM_BAPP) gv[e] = *reinterpret_cast<const float4*>(dout + off[e]);
                 if (BITS_IN) kv[e] = bits[off[e] >> 2];
-                else if (MODE != SM_STATS && keep) kv[e] = *reinterpret_cast<const uint32_t*>(keep + off[e]);
+                else if (MODE != SM_STATS && has_keep) kv[e] = *reinterpret_cast<const uint32_t*>(keep + off[e]);
             }
             __builtin_amdgcn_sched_barrier(0);
             const float* hp = hal[buf] + (wv * TH_H + 2 * tl + (q >> 3)) * TH_W + (q & 7);
@@ -509,10 +515,10 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                 if (BITS_IN) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) kp[j] = ((kv[e] >> j) & 1u) != 0;
-                } else if (MODE != SM_STATS && keep) {
+                } else if (MODE != SM_STATS && has_keep) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) kp[j] = ((kv[e] >> (8 * j)) & 0xffu) != 0;
-                } else if (MODE != SM_STATS && rk.on) {
+                } else if (MODE != SM_STATS && has_rk) {
                     const u4 r = philox4x32_10((uint64_t)(off[e] >> 2), rsid, rk.seed);
                     kp[0] = philox_keeps(r.x, p); kp[1] = philox_keeps(r.y, p);
                     kp[2] = philox_keeps(r.z, p); kp[3] = philox_keeps(r.w, p);
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(256, 3) void stem_bn_k(const float* __restrict__ a,
                 }
                 if ((MODE == SM_APPLY || MODE == SM_BAPP) && ok[e]) {
                     *reinterpret_cast<float4*>(out + off[e]) = make_float4(o[0], o[1], o[2], o[3]);
-                    if (MODE == SM_APPLY && out_bf16) thin_st_bf4(out_bf16, off[e], make_float4(o[0], o[1], o[2], o[3]));
+                    if (emit) thin_st_bf4(out_bf16, off[e], make_float4(o[0], o[1], o[2], o[3]));
                     if (MODE == SM_APPLY && BITS) bits[off[e] >> 2] = (uint8_t)pos;
                 }
             }
@@ -1603,10 +1609,17 @@ int stem_bnact_fwd_launch(const float* x, const float* w, const float* bias, con
                                 nbt, momentum, s);
         if (rc) return rc;
     }
-    if (bits)
-        stem_bn_k<SM_APPLY, true><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, nullptr, nullptr, 0.f, nullptr,
-                                                                  out, N, D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb,
-                                                                  (int)g.nbricks, (uint16_t*)out_bf16, (uint8_t*)bits);
+#define SIV_STEM_APPLY(...)                                                                                              \
+    stem_bn_k<SM_APPLY, __VA_ARGS__><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, nullptr, nullptr, 0.f, nullptr, \
+                                                                     out, N, D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb,        \
+                                                                     (int)g.nbricks, (uint16_t*)out_bf16, (uint8_t*)bits)
+    if (bits && rk.on && !keep && !out_bf16)            // training on the device generator, fp32 storage
+        SIV_STEM_APPLY(true, 2, 0);
+    else if (bits && rk.on && !keep)                    // ... bf16 storage
+        SIV_STEM_APPLY(true, 2, 1);
+    else if (bits)
+        SIV_STEM_APPLY(true);
+#undef SIV_STEM_APPLY
     else
         stem_bn_k<SM_APPLY><<<(unsigned)g.nblk, 256, 0, s>>>(x, w, bias, bn, keep, rk, p, nullptr, nullptr, 0.f, nullptr, out, N,
                                                             D, H, W, C, g.nbd, g.nbh, g.nbw, g.bpb, (int)g.nbricks,
