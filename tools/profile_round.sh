@@ -4,7 +4,7 @@
 # gpurun_out/; tools/summarize_profiles.py turns them into the files kept under profiles/.
 set -e
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
 timeout -k 10 400 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err

@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{TAG}")
 DST = os.path.join(ROOT, "profiles")
 DOM = "k3_fwd_wino2d"
