@@ -943,11 +943,16 @@ __global__ __launch_bounds__(256, 2) void c_to_one_zwalk12_k(const float* __rest
         }
         bw[g] = v;
     }
+    // Consecutive block ids go to different XCDs (each with an L2 of its own): an XCD is given a contiguous
+    // eighth of the columns instead, so that the halo voxels two neighbouring columns share are found in its L2.
     int b = blockIdx.x;
-    const int zp = b % zsplit; b /= zsplit;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    // (and within a sample the columns of one z segment follow each other: the blocks resident on an XCD at a
+    // time are then in-plane neighbours walking the same planes)
     const int tx = b % ntw; b /= ntw;
-    const int ty = b % nth;
-    const int n = b / nth;
+    const int ty = b % nth; b /= nth;
+    const int zp = b % zsplit;
+    const int n = b / zsplit;
     const int zlo = (int)((long)zp * D / zsplit), zhi = (int)((long)(zp + 1) * D / zsplit);
     const int y0 = ty * ZX_H, x0 = tx * ZX_W;
 
