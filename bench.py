@@ -43,6 +43,8 @@ def parse_args(argv=None):
     ap.add_argument("--graph", action="store_true",
                     help="single GPU: capture the iteration in a HIP graph and replay it (the per-kernel "
                          "event timing of the roofline fields is then taken from two eager iterations)")
+    ap.add_argument("--no-f2x4", action="store_true",
+                    help="skip the separately reported run with the opt-in F(2,3) x F(4,3) Winograd kernel")
     ap.add_argument("--split-bf16", action="store_true",
                     help="also time the opt-in conv path 5 (fp32 products from bf16 triples); never the headline")
     ap.add_argument("--rehearse-cpu", action="store_true",
@@ -459,6 +461,32 @@ def main():
                          "v_mfma_f32_32x32x16_bf16 (six piece products, fp32 accumulate; per-layer error vs fp64 "
                          "at or below that of the fp32 kernels); weight gradients and everything else unchanged"}
 
+    # Third, separately reported and NOT the headline either: the same iteration with the opt-in form of the
+    # forward / input-gradient Winograd kernel that applies F(4,3) along W (SIV_W2_W4=1: 9 instead of 12
+    # multiply-adds per output on the levels with 8 x 8 brick planes).  All fp32, per-layer rounding error that of
+    # the direct kernel, but at batch 1 the end-to-end gradient bounds of tests/test_gpu_fullsize.py are exceeded
+    # with it, so the default stays F(2x2).
+    f2x4 = None
+    if world == 1 and not rehearse and not args.no_f2x4 and graphed is None:
+        os.environ["SIV_W2_W4"] = "1"
+        try:
+            k3 = max(2, min(args.steps, 5))
+            one_step(0)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(k3):
+                last3 = one_step(1 + i)
+            barrier()
+            el3 = time.perf_counter() - t1
+        finally:
+            os.environ["SIV_W2_W4"] = "0"
+        st3 = dict(zip(trainer.STAT_NAMES, last3.cpu().tolist()))
+        f2x4 = {"value": round(args.batch * k3 / el3, 4), "unit": "volumes/s", "steps": k3,
+                "ms_per_step": round(1000.0 * el3 / k3, 2), "finite": all(v == v for v in st3.values()),
+                "what": "same iteration with SIV_W2_W4=1: forward / input-gradient convolutions of the 80x96x80 and "
+                        "40x48x40 levels on Winograd F(2,3) x F(4,3) (fp32 MFMA, 9 multiply-adds per output instead of "
+                        "12); opt-in, not the headline"}
+
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / args.steps
         vols = args.batch * world * args.steps / elapsed
@@ -524,6 +552,7 @@ def main():
             "roofline_step": roof_step,
             "roofline_hbm": roof_hbm,
             "split_bf16_products": split,
+            "winograd_f2x4": f2x4,
             "losses": {k: stats[k] for k in ("lossE", "lossD", "loss_rec", "kl_real")},
         }
         if rehearse:

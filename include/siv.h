@@ -41,7 +41,7 @@ typedef void* siv_stream_t;  /* hipStream_t */
 const char* siv_last_error(void);
 int siv_version(void);
 /* Name of the kernel family the calling thread's last 3x3x3 convolution entry point dispatched to
- * ("wino2d", "up", "up_wino", "wino", "wino_b3", "mfma", "thin", "generic"): lets tests assert that a
+ * ("wino2d", "wino2x4", "up", "up_wino", "wino", "wino_b3", "mfma", "thin", "generic"): lets tests assert that a
  * shape really ran on the kernel the automatic path is meant to pick.  No reference counterpart. */
 const char* siv_last_conv_kernel(void);
 /* Upper bound on the scratch any entry point needs for tensors up to the given size. */
@@ -55,7 +55,11 @@ size_t siv_workspace_bytes(void);
  * forward / input-gradient convolutions with Cin % 8 == 0 and Cout % 64 == 0 form their fp32
  * products from three bf16 pieces per operand on the bf16 matrix cores (fp32 accumulate; error of
  * the order of fp32 rounding, not bf16; opt-in), 6 = the large-volume kernels of path 0 (two-dimensional Winograd forward, input gradient and
- * weight gradient, product-form / box-form upsampled forward / input gradient) wherever they are supported, whatever the volume. */
+ * weight gradient, product-form / box-form upsampled forward / input gradient) wherever they are supported, whatever the volume.
+ * Environment SIV_W2_W4=1 (read at every call; opt-in): the two-dimensional Winograd forward / input-gradient kernel
+ * applies F(4,3) instead of F(2,3) along W on volumes it covers with 8 x 8 brick planes (9 instead of 12
+ * multiply-adds per output; fp32 throughout, rounding error of the order of the direct kernel's, 2-3 x that of
+ * the F(2x2) form); siv_last_conv_kernel() then reports "wino2x4". */
 int siv_set_conv_path(int path);
 
 /* ---- packed-weight cache ---------------------------------------------------------------------

@@ -490,6 +490,357 @@ __global__ __launch_bounds__(256) void k3_pack_weights_wino2d(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same kernel with F(4, 3) along W and F(2, 3) along H: a 2 x 4 output tile from a 4 x 6 patch,
+//   Y = A_h^T [ sum_kd (G_h g_kd G_w^T) .* (B_h^T d_kd B_w) ] A_w
+//   B_w^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G_w   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A_w^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// 24 positions x 3 planes = 72 multiply-adds per 8 outputs and channel pair: 9 per output instead of 12.
+//   M rows  = 2x4 output tiles of a 4x8x8-voxel brick: 8 per plane, 32 in all = ONE row tile
+//   a block = 8 waves: wave (ph, wn) owns the six positions (ph, 0..5) for output channel half wn
+//             (6 accumulators = 96 registers; 72 instead of 96 matrix instructions per chunk)
+//   V[pos][plane][tile][ci] of a chunk = 36 KB; staging items = (plane, tile, channel pair) = 192 = waves 0..2
+// Brick planes of 8 x 8 voxels only, no split of the channel contraction; everything else (raw halo image,
+// one chunk stream per block, epilogue between the live images, BatchNorm sums) as above.
+// ---------------------------------------------------------------------------------------------
+struct W4Cfg {
+    static constexpr int BD = 4, CK = 8;
+    static constexpr int TPP = 8, HD = BD + 2;
+    static constexpr int PLANE = HD * TPP * CK;            // floats of one position: 384
+    static constexpr int NPOS = 24;
+    static constexpr int V_FLOATS = NPOS * PLANE;          // 9216 floats = 36 KB
+    static constexpr int NTHR = 512, NT = 64;
+    static constexpr int TAPS = 72, SLICE = NT * 8;        // (kd, ph, pw) slices of [64 co][8 ci]
+    static constexpr int PD = 6;                           // weight fragments fetched PD taps ahead (divides 18)
+    static constexpr int EPI_STRIDE = 36, EPI_TILE = 32 * EPI_STRIDE;
+    static constexpr int RAW_ITEMS = 3 * NTHR, RAW_FLOATS = RAW_ITEMS * 4;      // 24 KB
+    // V0 | V1 | raw image 0 | padding | raw image 1: between two bricks V0 and raw image 1 are live and the
+    // epilogue has the 16 exchange tiles in between
+    static constexpr int PAD_FLOATS = 16 * EPI_TILE - V_FLOATS - RAW_FLOATS;     // 3072
+    static constexpr int RAW0 = 2 * V_FLOATS, RAW1 = RAW0 + RAW_FLOATS + PAD_FLOATS;
+    static constexpr int LDS_FLOATS = RAW1 + RAW_FLOATS;                         // 33792 floats = 132 KB
+    static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * sizeof(float);
+    static_assert(PAD_FLOATS >= 0, "exchange tiles fit between the live images");
+};
+
+#ifndef SIV_W4STAGE_T0
+#define SIV_W4STAGE_T0 5
+#endif
+
+__global__ __launch_bounds__(512, 2) void k3_fwd_wino2x4(const float* __restrict__ x,
+                                                         const float* __restrict__ wp,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ y, int N, int D, int H, int W,
+                                                         int Cin, int Cout, int nbd, int nbh, int nbw,
+                                                         int nbricks, float* __restrict__ stat_part) {
+    using C = W4Cfg;
+    constexpr int BHP = 10, BWP = 10, NV = C::HD * BHP * BWP;      // halo plane 10 x 10, 600 voxels
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    auto rawp = [&](int j) { return lds + (j ? C::RAW1 : C::RAW0); };
+    float* const epi = lds + C::V_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int ph = wave & 3, wn = wave >> 2;
+
+    auto item_of = [&](int b) { return (nbricks & 7) == 0 ? (b & 7) * (nbricks >> 3) + (b >> 3) : b; };
+    auto brick_of = [&](int b, int& bn, int& bz0, int& by0, int& bx0) {
+        b = item_of(b);
+        const int bx = b % nbw; b /= nbw;
+        const int by = b % nbh; b /= nbh;
+        bz0 = (b % nbd) * C::BD; by0 = by * 8; bx0 = bx * 8;
+        bn = b / nbd;
+    };
+    int vb = blockIdx.x;
+    const int cot = blockIdx.y;
+    int n, z0, y0, x0;
+    brick_of(vb, n, z0, y0, x0);
+    const int co0 = cot * C::NT;
+    const int nchunk = Cin / C::CK;
+
+    // A row m = li is tile (dz = m >> 3, th, tw) and reads V row (dz + kd) * 8 + tile = m + 8 kd
+    const int aoff = (ph * 6) * C::PLANE + li * C::CK + 4 * lh;          // + kd * 64 + pw * PLANE
+    const __amdgpu_buffer_rsrc_t wrs = buf_rsrc(wp, ((long)gridDim.y * nchunk + 1) * C::TAPS * C::SLICE * 4);
+    const unsigned wvo = ((ph * 6) * C::SLICE + (wn * 32 + li) * 8 + 4 * lh) * 4;
+    const int wso0 = cot * nchunk * C::TAPS * C::SLICE * 4;
+    constexpr int PD = C::PD;
+    float4 bring[PD];
+    auto tap_slice = [](int t) { return (t / 6) * 24 + t % 6; };        // slice of tap t = kd * 6 + pw (+ ph * 6 in wvo)
+
+    const long sample = (long)D * H * W * Cin;
+    __amdgpu_buffer_rsrc_t xrs = buf_rsrc(x + n * sample, sample * 4);
+    unsigned roff[3];
+    auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+    auto halo_offsets = [&](int bz0, int by0, int bx0) {
+        const int tid_ = opaque(tid);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int i = p * C::NTHR + tid_, v = i >> 1;
+            const int hx = v % BWP, hy = (v / BWP) % BHP, hz = v / (BWP * BHP);
+            const int gz = bz0 - 1 + hz, gy = by0 - 1 + hy, gx = bx0 - 1 + hx;
+            const bool ok = v < NV && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            roff[p] = ok ? (unsigned)((((gz * H + gy) * W + gx) * Cin + 4 * (i & 1)) * 4) : W2_OUTSIDE;
+        }
+    };
+    halo_offsets(z0, y0, x0);
+    float4 raw[3];
+    auto load_raw = [&](int c0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) raw[p] = buf_load16(xrs, roff[p], c0 * 4);
+    };
+    auto store_raw = [&](float* img) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<float4*>(img + (p * C::NTHR + tid) * 4) = raw[p];
+    };
+
+    // ---- staging item of this lane: (halo plane hz, tile (th, tw), channel pair qi); 192 items = waves 0..2
+    const bool s_on = wave < 3;
+    const int s_item = s_on ? wave * 64 + lane : 0;
+    const int s_qi = s_item & 3, s_r = s_item >> 2;                      // s_r = hz * 8 + th * 2 + tw
+    const int s_hz = s_r >> 3, s_th = (s_r & 7) >> 1, s_tw = s_r & 1;
+    const int rbase = ((s_hz * BHP + 2 * s_th) * BWP + 4 * s_tw) * C::CK + 2 * s_qi;
+    f32x2 patch[24];                                                      // [row 0..3][column 0..5]
+    auto read_patch = [&](const float* img) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                patch[rr * 6 + c] = *reinterpret_cast<const f32x2*>(img + rbase + (rr * BWP + c) * C::CK);
+    };
+    // pieces 0..3: patch row rr transformed along W in place (B_w^T); pieces 4..9: column pw finished along H
+    // (the rows of B_h^T as in the F(2x2) kernel) and its four positions written
+    auto stage_piece = [&](int piece, float* buf) {
+        const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, m4 = {-4.f, -4.f}, m5 = {-5.f, -5.f}, m2 = {-2.f, -2.f};
+        if (piece < 4) {
+            f32x2* d = patch + piece * 6;
+            const f32x2 a = pk_fma(m4, d[2], d[4]);            // d4 - 4 d2
+            const f32x2 b = pk_fma(m4, d[1], d[3]);            // d3 - 4 d1
+            const f32x2 c = d[4] - d[2];
+            const f32x2 e = d[3] - d[1];
+            const f32x2 t0 = pk_fma(k4, d[0], pk_fma(m5, d[2], d[4]));
+            const f32x2 t5 = pk_fma(k4, d[1], pk_fma(m5, d[3], d[5]));
+            d[0] = t0;
+            d[1] = a + b;
+            d[2] = a - b;
+            d[3] = pk_fma(k2, e, c);
+            d[4] = pk_fma(m2, e, c);
+            d[5] = t5;
+        } else {
+            const int pw = piece - 4;
+            float* dst = buf + s_r * C::CK + 2 * s_qi + pw * C::PLANE;
+            *reinterpret_cast<f32x2*>(dst + 0 * 6 * C::PLANE) = patch[0 * 6 + pw] - patch[2 * 6 + pw];
+            *reinterpret_cast<f32x2*>(dst + 1 * 6 * C::PLANE) = patch[1 * 6 + pw] + patch[2 * 6 + pw];
+            *reinterpret_cast<f32x2*>(dst + 2 * 6 * C::PLANE) = patch[2 * 6 + pw] - patch[1 * 6 + pw];
+            *reinterpret_cast<f32x2*>(dst + 3 * 6 * C::PLANE) = patch[1 * 6 + pw] - patch[3 * 6 + pw];
+        }
+    };
+
+    // ---- prologue (first brick of the block only)
+    load_raw(0);
+    f32x16 acc[6];             // [pw]
+    auto clear_acc = [&]() {
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 6; ++p) asm volatile("" : "+v"(acc[p]));
+    };
+    {
+        float4 raw1[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) raw1[p] = buf_load16(xrs, roff[p], (nchunk > 1 ? 1 : 0) * C::CK * 4);
+#pragma unroll
+        for (int i = 0; i < PD; ++i) bring[i] = buf_load16(wrs, wvo, wso0 + tap_slice(i) * C::SLICE * 4);
+        static_assert(18 % PD == 0, "ring index must not depend on the chunk");
+        __builtin_amdgcn_sched_barrier(0);
+        clear_acc();
+        __builtin_amdgcn_sched_barrier(0);
+        store_raw(rawp(0));
+#pragma unroll
+        for (int p = 0; p < 3; ++p) raw[p] = raw1[p];
+    }
+    store_raw(rawp(1));
+    __syncthreads();
+    if (s_on) {
+        read_patch(rawp(0));
+#pragma unroll
+        for (int piece = 0; piece < 10; ++piece) stage_piece(piece, lds);
+    }
+    __syncthreads();
+
+    for (;;) {
+        const int vnext = vb + (int)gridDim.x;
+        const bool has_next = vnext < nbricks;
+        int nn = n, nz0 = z0, ny0 = y0, nx0 = x0;
+        if (has_next) brick_of(vnext, nn, nz0, ny0, nx0);
+
+        for (int cc = 0; cc < nchunk; ++cc) {
+            const float* cur = lds + (cc & 1) * C::V_FLOATS;
+            float* nxt = lds + ((cc + 1) & 1) * C::V_FLOATS;
+            const float* rcur = rawp((cc + 1) & 1);                 // raw image of the next chunk of the stream
+            float* rnxt = rawp(cc & 1);                             // receives the chunk after next
+            const bool more = cc + 1 < nchunk || has_next;
+            const int wso = wso0 + cc * C::TAPS * C::SLICE * 4;
+            const int wsn = cc + 1 < nchunk ? wso + C::TAPS * C::SLICE * 4 : has_next ? wso0 : wso + C::TAPS * C::SLICE * 4;
+            float4 anext = *reinterpret_cast<const float4*>(cur + aoff);
+#pragma unroll
+            for (int t = 0; t < 18; ++t) {                     // t = kd * 6 + pw
+                const int pw = t % 6;
+                const float4 av = anext;
+                const float4 bv = bring[t % PD];
+                {   // fragment of tap t + PD
+                    const int tn = t + PD;
+                    bring[t % PD] = tn < 18 ? buf_load16(wrs, wvo, wso + tap_slice(tn) * C::SLICE * 4)
+                                            : buf_load16(wrs, wvo, wsn + tap_slice(tn - 18) * C::SLICE * 4);
+                }
+                if (t + 1 < 18) {
+                    const int t1 = t + 1;
+                    anext = *reinterpret_cast<const float4*>(cur + aoff + (t1 % 6) * C::PLANE + (t1 / 6) * 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[pw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[pw], 0, 0, 0);
+                acc[pw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[pw], 0, 0, 0);
+                acc[pw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[pw], 0, 0, 0);
+                acc[pw] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[pw], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == 0) {
+                    if (cc + 2 < nchunk) load_raw((cc + 2) * C::CK);
+                    else if (has_next) load_raw((cc + 2 - nchunk) * C::CK);
+                }
+                if (t == 16) store_raw(rnxt);
+                if (t == 17 && has_next && cc + 3 == nchunk) {
+                    halo_offsets(nz0, ny0, nx0);
+                    xrs = buf_rsrc(x + nn * sample, sample * 4);
+                }
+                if (more && s_on) {
+                    constexpr int T0 = SIV_W4STAGE_T0;
+                    if (t == T0) read_patch(rcur);
+                    if (t == T0 + 1) { stage_piece(0, nxt); stage_piece(1, nxt); }
+                    if (t == T0 + 2) { stage_piece(2, nxt); stage_piece(3, nxt); }
+                    if (t >= T0 + 3 && t <= T0 + 8) stage_piece(t - T0 + 1, nxt);
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- output transform and store: columns ow = 2 p + o of the tile in pass p
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int tid_ = opaque(tid);
+        const int lane = tid_ & 63, wave = tid_ >> 6;
+        const int li = lane & 31, lh = lane >> 5;
+        const int ph = wave & 3, wn = wave >> 2;
+        const int cq = lane & 7;
+        const int co = co0 + wn * 32 + 4 * cq;
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && co < Cout) bq = *reinterpret_cast<const float4*>(bias + co);
+        const int oh = ph & 1, owl = ph >> 1;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                float* tile = epi + ((ph * 2 + wn) * 2 + o) * C::EPI_TILE;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dm = acc[1][r] - acc[2][r], sm = acc[1][r] + acc[2][r];
+                    const float dn = acc[3][r] - acc[4][r], sn = acc[3][r] + acc[4][r];
+                    float v;
+                    if (p == 0 && o == 0) v = (acc[0][r] + sm) + sn;
+                    else if (p == 0) v = fmaf(2.f, dn, dm);
+                    else if (o == 0) v = fmaf(4.f, sn, sm);
+                    else v = fmaf(8.f, dn, dm) + acc[5][r];
+                    tile[((r & 3) + 8 * (r >> 2) + 4 * lh) * C::EPI_STRIDE + li] = v;
+                }
+            }
+            if (p == 1 && has_next) clear_acc();
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + (lane >> 3);
+                const int off = row * C::EPI_STRIDE + 4 * cq;
+                const float4 za = *reinterpret_cast<const float4*>(epi + (((oh + 0) * 2 + wn) * 2 + owl) * C::EPI_TILE + off);
+                const float4 zb = *reinterpret_cast<const float4*>(epi + (((oh + 1) * 2 + wn) * 2 + owl) * C::EPI_TILE + off);
+                const float4 zc = *reinterpret_cast<const float4*>(epi + (((oh + 2) * 2 + wn) * 2 + owl) * C::EPI_TILE + off);
+                float4 v = oh == 0 ? w2add(w2add(za, zb), zc) : w2sub(w2sub(za, zb), zc);
+                const int m = row;
+                const int gz = z0 + (m >> 3), gy = y0 + 2 * ((m & 7) >> 1) + oh, gx = x0 + 4 * (m & 1) + 2 * p + owl;
+                if (gz < D && gy < H && gx < W && co < Cout) {
+                    s1 = w2add(s1, v);
+                    s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y);
+                    s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+                    v = w2add(v, bq);
+                    *reinterpret_cast<float4*>(y + ((((long)n * D + gz) * H + gy) * W + gx) * Cout + co) = v;
+                }
+            }
+            __syncthreads();
+        }
+        if (stat_part) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64);
+                s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+                s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64);
+                s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+            }
+            float* red = epi;                  // [8 waves][2 (sum, sumsq)][32 channels]
+            if (lane < 8) {
+                *reinterpret_cast<float4*>(red + (wave * 2 + 0) * 32 + 4 * cq) = s1;
+                *reinterpret_cast<float4*>(red + (wave * 2 + 1) * 32 + 4 * cq) = s2;
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const int k = tid >> 6, c = tid & 63, w0 = (c >> 5) * 4;
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s += red[((w0 + q) * 2 + k) * 32 + (c & 31)];
+                if (co0 + c < Cout) stat_part[((long)vb * 2 + k) * Cout + co0 + c] = s;
+            }
+            __syncthreads();
+        }
+        if (!has_next) break;
+        vb = vnext; n = nn; z0 = nz0; y0 = ny0; x0 = nx0;
+    }
+}
+
+// wp[ct][cc][kd*24 + ph*6 + pw][co (64)][ci (8)] = (G_h g_kd G_w^T)[ph][pw]; g as in k3_pack_weights_wino2d
+__global__ __launch_bounds__(256) void k3_pack_weights_wino2x4(const float* __restrict__ w,
+                                                               float* __restrict__ wp, int Kin, int Kout,
+                                                               int flip) {
+    const int nchunk = Kin / 8, ntile = Kout / 64;
+    const long total = (long)ntile * nchunk * 72 * 64 * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        long r = i >> 3;
+        const int co = (int)(r & 63); r >>= 6;
+        const int t = (int)(r % 72); r /= 72;
+        const int cc = (int)(r % nchunk);
+        const int ct = (int)(r / nchunk);
+        const int pw = t % 6, ph = (t / 6) % 4, kd = t / 24;
+        const int kco = ct * 64 + co, kci = cc * 8 + j;
+        float g[3][3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tap = (kd * 3 + kh) * 3 + kw;
+                g[kh][kw] = flip ? w[((long)kci * 27 + (26 - tap)) * Kout + kco] : w[((long)kco * 27 + tap) * Kin + kci];
+            }
+        // rows of G_w along kw (in double: 1/6 and 1/24 are not exact), then rows of G_h along kh
+        double u[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const double g0 = g[kh][0], g1 = g[kh][1], g2 = g[kh][2];
+            u[kh] = pw == 0 ? g0 / 4.0 : pw == 1 ? -(g0 + g1 + g2) / 6.0 : pw == 2 ? (-g0 + g1 - g2) / 6.0
+                  : pw == 3 ? g0 / 24.0 + g1 / 12.0 + g2 / 6.0 : pw == 4 ? g0 / 24.0 - g1 / 12.0 + g2 / 6.0 : g2;
+        }
+        const double v = ph == 0 ? u[0] : ph == 1 ? 0.5 * (u[0] + u[1] + u[2]) : ph == 2 ? 0.5 * (u[0] - u[1] + u[2]) : u[2];
+        wp[i] = (float)v;
+    }
+}
+
 // SIV_W2CHAIN=0 (build flag) launches one block per brick as before
 #ifndef SIV_W2CHAIN
 #define SIV_W2CHAIN 1
@@ -497,8 +848,14 @@ __global__ __launch_bounds__(256) void k3_pack_weights_wino2d(const float* __res
 constexpr bool W2_CHAIN = SIV_W2CHAIN != 0;
 constexpr long W2_CUS = 256;           // CUs of the device (gfx950)
 bool k3_fwd_wino2d_supported(int Cin, int Cout) { return Cin % 8 == 0 && Cout % 64 == 0; }
-size_t k3_fwd_wino2d_ws_bytes(int Cin, int Cout) {     // one chunk of padding behind the last slice
-    return ((size_t)(Cout / 64) * (Cin / 8) + 1) * 48 * 512 * sizeof(float);
+size_t k3_fwd_wino2d_ws_bytes(int Cin, int Cout) {     // one chunk of padding behind the last slice (72: the F(2x4) form)
+    return ((size_t)(Cout / 64) * (Cin / 8) + 1) * 72 * 512 * sizeof(float);
+}
+// SIV_W2_W4=1 (environment, read at every launch): F(4,3) along W for the layers with 8 x 8 brick planes and an
+// unsplit contraction
+static bool w2d_use_w4() {
+    const char* e = getenv("SIV_W2_W4");
+    return e && e[0] == '1';
 }
 
 // Brick planes of 6 x 10 voxels where they pad the volume less than 8 x 8 ones (10- and 20-wide levels).
@@ -595,6 +952,40 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
                          float* stat_part, void* kws, size_t kws_bytes) {
     SIV_CHECK_WS(k3_fwd_wino2d_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(winograd 2-D)");
     SIV_CHECK_ARG((long)D * H * W * Cin < (1L << 29), "conv3d_k3(winograd 2-D): sample too large for 32-bit byte offsets");
+    if (w2d_use_w4() && w2d_tpr(H, W) == 4 && (Cin / 8) % 2 == 0 && Cin >= 32 &&
+        w2d_kshift(k3_fwd_wino2d_bricks(N, D, H, W), (long)N * D * H * W, Cin, Cout) == 0) {
+        const long total4 = (long)(Cout / 64) * (Cin / 8) * 72 * 512;
+        long g4 = cdiv(total4, 256);
+        if (g4 > 4096) g4 = 4096;
+        bool need;
+        const float* wpk4 = (const float*)pack_slot(w, PF_WINO2D, 1, flip, Cin, Cout, k3_fwd_wino2d_ws_bytes(Cin, Cout), ws, &need);
+        if (need) {
+            k3_pack_weights_wino2x4<<<(unsigned)g4, 256, 0, s>>>(w, const_cast<float*>(wpk4), Cin, Cout, flip);
+            SIV_CHECK_PACK_LAUNCH("conv3d_k3(pack F(2x4) winograd weights)", wpk4);
+        }
+        const int nbd = (D + 3) / 4, nbh = (int)cdiv(H, 8), nbw = (int)cdiv(W, 8);
+        const long nbricks = (long)N * nbd * nbh * nbw;
+        if (nbricks > 0x7fffffffL) {
+            set_error("conv3d_k3(winograd 2-D): too many bricks");
+            return SIV_EINVAL;
+        }
+        long nblk = nbricks;
+        const int ncot = Cout / 64;
+        if (nbricks * ncot > W2_CUS) {
+            const long g = (W2_CUS / ncot) & ~7L;
+            if (g >= 8 && g < nbricks) nblk = g;
+        }
+        if (hipFuncSetAttribute((const void*)k3_fwd_wino2x4, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)W4Cfg::LDS_BYTES) != hipSuccess) {
+            set_error("conv3d_k3(winograd F(2x4)): cannot reserve %zu bytes of LDS", W4Cfg::LDS_BYTES);
+            return SIV_EHIP;
+        }
+        k3_fwd_wino2x4<<<dim3((unsigned)nblk, (unsigned)ncot), 512, W4Cfg::LDS_BYTES, s>>>(
+            x, wpk4, bias, y, N, D, H, W, Cin, Cout, nbd, nbh, nbw, (int)nbricks, stat_part);
+        SIV_CHECK_LAUNCH("conv3d_k3(winograd F(2x4))");
+        note_conv_kernel("wino2x4");
+        return SIV_OK;
+    }
     const long total = (long)(Cout / 64) * (Cin / 8) * 48 * 512;
     long g = cdiv(total, 256);
     if (g > 4096) g = 4096;

@@ -16,6 +16,8 @@ static std::atomic<int> g_conv_path{0};
 // kernel family the last 3x3x3 convolution entry point of this thread dispatched to (for tests)
 static thread_local const char* g_conv_kernel = "";
 #define SIV_PICK(name) (g_conv_kernel = (name))
+// (a launcher that chooses between forms of its family names the one it took)
+void note_conv_kernel(const char* name) { g_conv_kernel = name; }
 
 void set_error(const char* fmt, ...) {
     va_list ap;

@@ -48,6 +48,7 @@ void* pack_slot(const void* w, int family, int variant, int flip, int Cin, int C
 // A packing kernel that was to fill `slot` did not launch: the cache forgets the slot, so that no later
 // call takes it for a finished packing.
 void pack_slot_failed(const void* slot);
+void note_conv_kernel(const char* name);      // overrides the name siv_last_conv_kernel() reports for this call
 // to be used right after the launch of a packing kernel whose destination came from pack_slot
 #define SIV_CHECK_PACK_LAUNCH(what, slot)                                                \
     do {                                                                                 \

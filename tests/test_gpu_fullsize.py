@@ -84,6 +84,48 @@ def test_benchmark_conv_shapes_match_oracle(B, cin, cout, dims, n, ups, kern):
           + ", ".join(f"{k} {v:.1e}" for k, v in e.items()))
 
 
+@pytest.mark.parametrize("cin,cout,dims,n", [(64, 64, V0, 1), (64, 64, V1, 8), (64, 128, V1, 8), (128, 64, V1, 4),
+                                             (64, 64, (13, 22, 23), 2), (32, 64, (8, 16, 24), 3)])
+def test_opt_in_winograd_f2x4_matches_oracle(B, cin, cout, dims, n, monkeypatch):
+    """The opt-in form of the two-dimensional Winograd kernel with F(4,3) along W (SIV_W2_W4=1): forward (with
+    bias) and input gradient of nn.Conv3d(k=3,s=1,p=1) (models/models.py:17,21) at the benchmark's 80x96x80 and
+    40x48x40 shapes and on ragged volumes against the oracle at the same 1e-4 of max as every other kernel,
+    the BatchNorm sums of its epilogue, and the name the library reports for it."""
+    import ctypes
+    import siv._lib as L
+    monkeypatch.setenv("SIV_W2_W4", "1")
+    gen = torch.Generator().manual_seed(cin + cout + dims[0] + n)
+    x = torch.randn(n, cin, *dims, generator=gen)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=gen) * (2.0 / (27 * cin)) ** 0.5
+    b = torch.randn(cout, generator=gen)
+    dy = torch.randn(n, cout, *dims, generator=gen)
+    lib = L.load()
+    lib.siv_last_conv_kernel.restype = ctypes.c_char_p
+    B.set_conv_path(6)                  # the large-volume kernels whatever the volume
+    try:
+        y = B.conv3d_k3_fwd(x.cuda(), w.cuda(), b.cuda(), 1)
+        assert lib.siv_last_conv_kernel() == b"wino2x4"
+        dx = B.conv3d_k3_dgrad(dy.cuda(), w.cuda(), 1)
+        # (the input gradient is a convolution cout -> cin: the Winograd kernels want 64-channel output tiles)
+        assert lib.siv_last_conv_kernel() == (b"wino2x4" if cin % 64 == 0 else b"mfma")
+        rm, rv, nbt = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda"), torch.tensor(0, device="cuda")
+        y2, mean, var = B.conv3d_k3_fwd_stats(x.cuda(), w.cuda(), b.cuda(), 1, rm, rv, nbt, 0.1)
+    finally:
+        B.set_conv_path(0)
+    xr = x.clone().requires_grad_(True)
+    yr = O.conv3d_k3(xr, w, b, 1)
+    yr.backward(dy)
+    check_max(y, yr.detach(), "forward", tol=1e-4)
+    check_max(dx, xr.grad, "input gradient", tol=1e-4)
+    assert torch.equal(y2, y)
+    check_max(mean, yr.detach().double().mean(dim=(0, 2, 3, 4)).float(), "batch mean", tol=1e-4, floor=1e-6)
+    check_max(var, yr.detach().double().var(dim=(0, 2, 3, 4), unbiased=False).float(), "batch variance", tol=1e-4)
+    monkeypatch.setenv("SIV_W2_W4", "0")
+    y0 = B.conv3d_k3_fwd(x.cuda(), w.cuda(), b.cuda(), 1)
+    assert lib.siv_last_conv_kernel() != b"wino2x4"
+    check_max(y0, yr.detach(), "forward, default form", tol=1e-4)
+
+
 Z1200 = (64, [[64, 1, 2], [128, 1, 2], [256, 2, 2]])       # z-1200main.py:158
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
