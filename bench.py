@@ -131,7 +131,10 @@ def step_flops_per_volume():
         for cin, cout, vox, ups in layers:
             f = 2.0 * 27 * cin * cout * vox
             alg += f * (nf + nd + nw)
-            iss += f * ((nf + nd) * (UPS_ISSUED if ups == 2 else WINO2D_ISSUED)
+            # non-upsampled input gradients at the 80x96x80 and 40x48x40 levels run the F(2,3) x F(4,3) form of
+            # the Winograd kernel by default: 9 instead of 12 of the 27 multiply-adds
+            dg = 9.0 / 27.0 if (ups == 1 and vox >= v1 and os.environ.get("SIV_W2_W4", "2") in ("1", "2")) else WINO2D_ISSUED
+            iss += f * (nf * (UPS_ISSUED if ups == 2 else WINO2D_ISSUED) + nd * (UPS_ISSUED if ups == 2 else dg)
                         + nw * (UPS_ISSUED if ups == 2 else WGRAD_ISSUED))
     return alg, iss
 
@@ -461,13 +464,13 @@ def main():
                          "v_mfma_f32_32x32x16_bf16 (six piece products, fp32 accumulate; per-layer error vs fp64 "
                          "at or below that of the fp32 kernels); weight gradients and everything else unchanged"}
 
-    # Third, separately reported and NOT the headline either: the same iteration with the opt-in form of the
-    # forward / input-gradient Winograd kernel that applies F(4,3) along W (SIV_W2_W4=1: 9 instead of 12
-    # multiply-adds per output on the levels with 8 x 8 brick planes).  All fp32, per-layer rounding error that of
-    # the direct kernel, but at batch 1 the end-to-end gradient bounds of tests/test_gpu_fullsize.py are exceeded
-    # with it, so the default stays F(2x2).
+    # Third, separately reported and NOT the headline either: the same iteration with the FORWARD convolutions of
+    # the 80x96x80 and 40x48x40 levels on the F(2,3) x F(4,3) form of the Winograd kernel too (SIV_W2_W4=1; the
+    # default applies it to the input gradients only).  All fp32, per-layer rounding error that of the direct
+    # kernel, but at batch 1 the end-to-end gradient bounds of tests/test_gpu_fullsize.py are exceeded with it.
     f2x4 = None
     if world == 1 and not rehearse and not args.no_f2x4 and graphed is None:
+        w4_before = os.environ.get("SIV_W2_W4")
         os.environ["SIV_W2_W4"] = "1"
         try:
             k3 = max(2, min(args.steps, 5))
@@ -479,13 +482,16 @@ def main():
             barrier()
             el3 = time.perf_counter() - t1
         finally:
-            os.environ["SIV_W2_W4"] = "0"
+            if w4_before is None:
+                del os.environ["SIV_W2_W4"]
+            else:
+                os.environ["SIV_W2_W4"] = w4_before
         st3 = dict(zip(trainer.STAT_NAMES, last3.cpu().tolist()))
         f2x4 = {"value": round(args.batch * k3 / el3, 4), "unit": "volumes/s", "steps": k3,
                 "ms_per_step": round(1000.0 * el3 / k3, 2), "finite": all(v == v for v in st3.values()),
-                "what": "same iteration with SIV_W2_W4=1: forward / input-gradient convolutions of the 80x96x80 and "
-                        "40x48x40 levels on Winograd F(2,3) x F(4,3) (fp32 MFMA, 9 multiply-adds per output instead of "
-                        "12); opt-in, not the headline"}
+                "what": "same iteration with SIV_W2_W4=1: the forward convolutions of the 80x96x80 and 40x48x40 levels "
+                        "on Winograd F(2,3) x F(4,3) too (the default applies it to the input gradients only); fp32 "
+                        "MFMA, 9 multiply-adds per output instead of 12; opt-in, not the headline"}
 
     if rank == 0:
         ms_per_step = 1000.0 * elapsed / args.steps

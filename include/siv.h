@@ -56,10 +56,11 @@ size_t siv_workspace_bytes(void);
  * products from three bf16 pieces per operand on the bf16 matrix cores (fp32 accumulate; error of
  * the order of fp32 rounding, not bf16; opt-in), 6 = the large-volume kernels of path 0 (two-dimensional Winograd forward, input gradient and
  * weight gradient, product-form / box-form upsampled forward / input gradient) wherever they are supported, whatever the volume.
- * Environment SIV_W2_W4=1 (read at every call; opt-in): the two-dimensional Winograd forward / input-gradient kernel
- * applies F(4,3) instead of F(2,3) along W on volumes it covers with 8 x 8 brick planes (9 instead of 12
- * multiply-adds per output; fp32 throughout, rounding error of the order of the direct kernel's, 2-3 x that of
- * the F(2x2) form); siv_last_conv_kernel() then reports "wino2x4". */
+ * Environment SIV_W2_W4 (read at every call): on volumes it covers with 8 x 8 brick planes the two-dimensional
+ * Winograd kernel can apply F(4,3) instead of F(2,3) along W (9 instead of 12 multiply-adds per output; fp32
+ * throughout, rounding error of the order of the direct kernel's, 2-3 x that of the F(2x2) form).  Unset or "2":
+ * the input gradients do (default), "1": forward too (opt-in: forward rounding is what LeakyReLU kinks and
+ * BatchNorm statistics amplify), "0": neither.  siv_last_conv_kernel() reports "wino2x4" for such a call. */
 int siv_set_conv_path(int path);
 
 /* ---- packed-weight cache ---------------------------------------------------------------------

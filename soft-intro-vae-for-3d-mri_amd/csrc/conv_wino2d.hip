@@ -851,11 +851,17 @@ bool k3_fwd_wino2d_supported(int Cin, int Cout) { return Cin % 8 == 0 && Cout % 
 size_t k3_fwd_wino2d_ws_bytes(int Cin, int Cout) {     // one chunk of padding behind the last slice (72: the F(2x4) form)
     return ((size_t)(Cout / 64) * (Cin / 8) + 1) * 72 * 512 * sizeof(float);
 }
-// SIV_W2_W4=1 (environment, read at every launch): F(4,3) along W for the layers with 8 x 8 brick planes and an
-// unsplit contraction
-static bool w2d_use_w4() {
+// Which convolutions take the F(2,3) x F(4,3) form on volumes with 8 x 8 brick planes and an unsplit contraction
+// (environment SIV_W2_W4, read at every launch): unset or "2" = the input gradients, "1" = forward too, "0" =
+// none.  The input gradients are the default because their rounding adds to a gradient once, linearly, while
+// forward rounding moves activations across LeakyReLU kinks and BatchNorm statistics: at batch 1 the end-to-end
+// gradients of the benchmark model move by up to 3.5 % of a tensor's maximum with the F(2x4) forward (0.8 % with
+// F(2x2), 1.5 % with the direct kernels, 0.6 % for the fp32 reference itself), and not at all with the F(2x4)
+// input gradient.
+static bool w2d_use_w4(int flip) {
     const char* e = getenv("SIV_W2_W4");
-    return e && e[0] == '1';
+    const char m = e && e[0] ? e[0] : '2';
+    return m == '1' || (m == '2' && flip);
 }
 
 // Brick planes of 6 x 10 voxels where they pad the volume less than 8 x 8 ones (10- and 20-wide levels).
@@ -952,7 +958,7 @@ int k3_fwd_wino2d_launch(const float* x, const float* w, const float* bias, floa
                          float* stat_part, void* kws, size_t kws_bytes) {
     SIV_CHECK_WS(k3_fwd_wino2d_ws_bytes(Cin, Cout), ws_bytes, "conv3d_k3(winograd 2-D)");
     SIV_CHECK_ARG((long)D * H * W * Cin < (1L << 29), "conv3d_k3(winograd 2-D): sample too large for 32-bit byte offsets");
-    if (w2d_use_w4() && w2d_tpr(H, W) == 4 && (Cin / 8) % 2 == 0 && Cin >= 32 &&
+    if (w2d_use_w4(flip) && w2d_tpr(H, W) == 4 && (Cin / 8) % 2 == 0 && Cin >= 32 &&
         w2d_kshift(k3_fwd_wino2d_bricks(N, D, H, W), (long)N * D * H * W, Cin, Cout) == 0) {
         const long total4 = (long)(Cout / 64) * (Cin / 8) * 72 * 512;
         long g4 = cdiv(total4, 256);

@@ -27,7 +27,7 @@ V0, V1, V2, V3 = (80, 96, 80), (40, 48, 40), (20, 24, 20), (10, 12, 10)
 FULL_CONV_CASES = [
     (1, 64, V0, 1, 1, ("thin", "thin", "thin")),                  # encoder stem (models/models.py:92)
     (64, 1, V0, 1, 1, ("thin", "thin", "thin")),                  # decoder output layer (:137)
-    (64, 64, V0, 1, 1, ("wino2d", "wino2d", "wino2d")),           # encoder block 1, conv 1 (:17)
+    (64, 64, V0, 1, 1, ("wino2d", "wino2x4", "wino2d")),          # encoder block 1, conv 1 (:17)
     (64, 64, V0, 1, 2, ("up", "up", "up_wino")),                  # decoder last block, conv 2 (:57-59)
     (64, 64, V1, 2, 1, ("wino2d", "wino2d", "wino2d")),
     (64, 128, V1, 2, 1, ("wino2d", "wino2d", "wino2d")),
@@ -87,10 +87,11 @@ def test_benchmark_conv_shapes_match_oracle(B, cin, cout, dims, n, ups, kern):
 @pytest.mark.parametrize("cin,cout,dims,n", [(64, 64, V0, 1), (64, 64, V1, 8), (64, 128, V1, 8), (128, 64, V1, 4),
                                              (64, 64, (13, 22, 23), 2), (32, 64, (8, 16, 24), 3)])
 def test_opt_in_winograd_f2x4_matches_oracle(B, cin, cout, dims, n, monkeypatch):
-    """The opt-in form of the two-dimensional Winograd kernel with F(4,3) along W (SIV_W2_W4=1): forward (with
-    bias) and input gradient of nn.Conv3d(k=3,s=1,p=1) (models/models.py:17,21) at the benchmark's 80x96x80 and
-    40x48x40 shapes and on ragged volumes against the oracle at the same 1e-4 of max as every other kernel,
-    the BatchNorm sums of its epilogue, and the name the library reports for it."""
+    """The form of the two-dimensional Winograd kernel with F(4,3) along W -- the default for input gradients,
+    opt-in for forward (SIV_W2_W4=1): forward (with bias) and input gradient of nn.Conv3d(k=3,s=1,p=1)
+    (models/models.py:17,21) at the benchmark's 80x96x80 and 40x48x40 shapes (batch 8 at the latter: the shapes
+    the benchmark runs unsplit) and on ragged volumes against the oracle at the same 1e-4 of max as every other
+    kernel, the BatchNorm sums of its epilogue, the name the library reports, and which calls take it by default."""
     import ctypes
     import siv._lib as L
     monkeypatch.setenv("SIV_W2_W4", "1")
@@ -120,10 +121,22 @@ def test_opt_in_winograd_f2x4_matches_oracle(B, cin, cout, dims, n, monkeypatch)
     assert torch.equal(y2, y)
     check_max(mean, yr.detach().double().mean(dim=(0, 2, 3, 4)).float(), "batch mean", tol=1e-4, floor=1e-6)
     check_max(var, yr.detach().double().var(dim=(0, 2, 3, 4), unbiased=False).float(), "batch variance", tol=1e-4)
-    monkeypatch.setenv("SIV_W2_W4", "0")
-    y0 = B.conv3d_k3_fwd(x.cuda(), w.cuda(), b.cuda(), 1)
-    assert lib.siv_last_conv_kernel() != b"wino2x4"
+    # default: the input gradient takes it, forward does not; "0": neither
+    monkeypatch.delenv("SIV_W2_W4")
+    B.set_conv_path(6)
+    try:
+        y0 = B.conv3d_k3_fwd(x.cuda(), w.cuda(), b.cuda(), 1)
+        assert lib.siv_last_conv_kernel() == b"wino2d"
+        dx0 = B.conv3d_k3_dgrad(dy.cuda(), w.cuda(), 1)
+        assert lib.siv_last_conv_kernel() == (b"wino2x4" if cin % 64 == 0 else b"mfma")
+        monkeypatch.setenv("SIV_W2_W4", "0")
+        dx1 = B.conv3d_k3_dgrad(dy.cuda(), w.cuda(), 1)
+        assert lib.siv_last_conv_kernel() == (b"wino2d" if cin % 64 == 0 else b"mfma")
+    finally:
+        B.set_conv_path(0)
     check_max(y0, yr.detach(), "forward, default form", tol=1e-4)
+    assert torch.equal(dx0, dx)
+    check_max(dx1, xr.grad, "input gradient, F(2x2) form", tol=1e-4)
 
 
 Z1200 = (64, [[64, 1, 2], [128, 1, 2], [256, 2, 2]])       # z-1200main.py:158

@@ -74,7 +74,7 @@ Produced by `tools/profile_round.sh` on one MI355X, summarised by `tools/summari
 `{json.dumps({k: bench[k] for k in ("value", "unit", "ms_per_step", "roofline", "cpu_baseline")})}`
 
 ## rocprofv3 --kernel-trace --stats of `bench.py --steps 3 --warmup 1`
-* launches of this kernel at the dominant shape (grid {DOM_GRID}, forward and input gradient), weight
+* launches of this kernel at the dominant shape (grid {DOM_GRID}; forward -- the input gradients run the F(2,3) x F(4,3) form, `k3_fwd_wino2x4`), weight
   gradients on the main stream (`SIV_OVERLAP_WGRAD=0`, every launch alone on the chip): {len(durs)}, average
   **{avg_ms:.3f} ms** (bench.py's live HIP-event figure over the forward launches: {bench["roofline"]["avg_launch_ms"]} ms)
   = {ALGO_FLOP / avg_ms / 1e9:.1f} TFLOP/s algorithmic; in the default run the backward launches share the chip with
