@@ -512,7 +512,10 @@ struct W4Cfg {
     static constexpr int V_FLOATS = NPOS * PLANE;          // 9216 floats = 36 KB
     static constexpr int NTHR = 512, NT = 64;
     static constexpr int TAPS = 72, SLICE = NT * 8;        // (kd, ph, pw) slices of [64 co][8 ci]
-    static constexpr int PD = 6;                           // weight fragments fetched PD taps ahead (divides 18)
+#ifndef SIV_W4PD
+#define SIV_W4PD 6
+#endif
+    static constexpr int PD = SIV_W4PD;                    // weight fragments fetched PD taps ahead (divides 18)
     static constexpr int EPI_STRIDE = 36, EPI_TILE = 32 * EPI_STRIDE;
     static constexpr int RAW_ITEMS = 3 * NTHR, RAW_FLOATS = RAW_ITEMS * 4;      // 24 KB
     // V0 | V1 | raw image 0 | padding | raw image 1: between two bricks V0 and raw image 1 are live and the
@@ -525,7 +528,7 @@ struct W4Cfg {
 };
 
 #ifndef SIV_W4STAGE_T0
-#define SIV_W4STAGE_T0 5
+#define SIV_W4STAGE_T0 8
 #endif
 
 __global__ __launch_bounds__(512, 2) void k3_fwd_wino2x4(const float* __restrict__ x,
